@@ -1,0 +1,90 @@
+"""Device-buffer plumbing: PyTorch-ROCm tensors are used only as allocations."""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise _lib.AgxError('no ROCm GPU visible: the agx hot path runs only on an MI355X (gfx950); '
+                            'there is no CPU fallback')
+    idx = torch.cuda.current_device()
+    _lib.init_device(idx)
+    return torch.device('cuda', idx)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def r4(n):
+    return (int(n) + 3) & ~3
+
+
+def empty(shape, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=device())
+
+
+def zeros(shape, dtype=torch.float32):
+    return torch.zeros(shape, dtype=dtype, device=device())
+
+
+def to_dev(a, dtype=torch.float32):
+    """Host NumPy / torch tensor -> contiguous device tensor of `dtype`."""
+    dev = device()
+    if isinstance(a, DeviceArray):
+        a = a.tensor
+    if isinstance(a, torch.Tensor):
+        return a.to(device=dev, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype={
+        torch.float32: np.float32, torch.int32: np.int32, torch.float64: np.float64}[dtype])).to(dev)
+
+
+def padded_matrix(a):
+    """[N, G] host/device fp32 matrix -> device tensor [N, r4(G)] (16-B aligned rows)."""
+    t = to_dev(a)
+    if t.dim() != 2:
+        raise ValueError('expected a 2-D matrix, got shape %s' % (tuple(t.shape),))
+    n, g = t.shape
+    ld = r4(g)
+    if ld == g:
+        return t, ld
+    out = torch.zeros((n, ld), dtype=torch.float32, device=t.device)
+    out[:, :g] = t
+    return out, ld
+
+
+class DeviceArray:
+    """Result living in HBM; converts lazily (the only host sync is the conversion)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(str(self.tensor.dtype).replace('torch.', ''))
+
+    def numpy(self):
+        return self.tensor.detach().cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __float__(self):
+        return float(self.numpy().reshape(-1)[0])
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return 'DeviceArray(shape=%s)' % (self.shape,)

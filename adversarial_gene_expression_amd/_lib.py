@@ -1,0 +1,160 @@
+"""ctypes binding of libagx.so (declared in include/agx.h).
+
+The HIP library is the product: if it is missing or fails to load this module
+raises - there is no CPU fallback anywhere in the package.  PyTorch-ROCm is
+used only to own device memory and streams (and torch.distributed for RCCL).
+"""
+import ctypes as C
+import os
+
+AGX_MAX_LAYERS = 8
+AGX_MAX_CAT = 16
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libagx.so')
+
+
+class AgxError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p),
+        ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+        ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32),
+        ('ta', C.c_int32), ('tb', C.c_int32),
+        ('alpha', C.c_float),
+        ('bias', C.c_void_p),
+        ('addrow', C.c_void_p),
+        ('addmod', C.c_int32), ('ldadd', C.c_int32),
+        ('act', C.c_int32),
+        ('slope', C.c_float),
+        ('mask', C.c_void_p),
+        ('ldmask', C.c_int32),
+        ('accumulate', C.c_int32),
+        ('ws', C.c_void_p),
+        ('ws_floats', C.c_int64),
+        ('force_cfg', C.c_int32),
+        ('force_splitk', C.c_int32),
+    ]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [
+        ('n_cat', C.c_int32),
+        ('vocab', C.c_int32 * AGX_MAX_CAT),
+        ('edim', C.c_int32 * AGX_MAX_CAT),
+        ('table_off', C.c_int64 * AGX_MAX_CAT),
+    ]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ('n_layers', C.c_int32),
+        ('dims', C.c_int32 * (AGX_MAX_LAYERS + 1)),
+        ('ldw', C.c_int32 * AGX_MAX_LAYERS),
+        ('w_off', C.c_int64 * AGX_MAX_LAYERS),
+        ('b_off', C.c_int64 * AGX_MAX_LAYERS),
+        ('emb', EmbedDesc),
+        ('n_num', C.c_int32),
+        ('n_flat', C.c_int64),
+    ]
+
+
+class CganConfig(C.Structure):
+    _fields_ = [
+        ('x_dim', C.c_int32), ('z_dim', C.c_int32),
+        ('gen', MlpDesc), ('disc', MlpDesc),
+        ('slope', C.c_float),
+        ('max_batch', C.c_int32),
+    ]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ('x', C.c_void_p), ('ldx', C.c_int32),
+        ('z', C.c_void_p), ('cat', C.c_void_p), ('num', C.c_void_p), ('alpha', C.c_void_p),
+        ('B', C.c_int32), ('B_global', C.c_int32),
+        ('gp_weight', C.c_float),
+        ('aug_mask', C.c_void_p), ('aug_noise_fake', C.c_void_p), ('aug_noise_real', C.c_void_p),
+        ('losses', C.c_void_p),
+    ]
+
+
+_vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); every symbol include/agx.h declares
+SIGNATURES = {
+    'agx_version': (C.c_int, []),
+    'agx_last_error': (C.c_char_p, []),
+    'agx_init': (C.c_int, [C.c_int]),
+    'agx_gemm_f32': (C.c_int, [_vp, C.POINTER(GemmDesc)]),
+    'agx_gemm_ws_floats': (_i64, [_i32, _i32, _i32]),
+    'agx_embed_concat_fwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32,
+                                       _vp, _i32, _i32, _i32, _vp, _i32]),
+    'agx_embed_bwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32]),
+    'agx_gp_interp': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32]),
+    'agx_aug_add': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32]),
+    'agx_rowdot': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32]),
+    'agx_delta_init': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32]),
+    'agx_gp_rownorm_scale': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32]),
+    'agx_wgan_loss': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _f32, _f32, _vp]),
+    'agx_colsum': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32]),
+    'agx_colsum_weighted': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp]),
+    'agx_opt_rmsprop': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32]),
+    'agx_opt_adam': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32]),
+    'agx_rng_normal': (C.c_int, [_vp, _vp, _i64, _u64, _u64]),
+    'agx_rng_uniform': (C.c_int, [_vp, _vp, _i64, _u64, _u64]),
+    'agx_colstats': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'agx_standardize': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
+    'agx_corr_xtx': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i64, _i64]),
+    'agx_corr_num_tiles': (_i64, [_i32]),
+    'agx_triu_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'agx_pearson_sums': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    'agx_gamma_sums': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    'agx_cgan_create': (C.c_int, [C.POINTER(CganConfig), C.POINTER(_vp)]),
+    'agx_cgan_destroy': (C.c_int, [_vp]),
+    'agx_cgan_workspace_bytes': (_i64, [_vp]),
+    'agx_cgan_bind': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    'agx_cgan_gen_forward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
+    'agx_cgan_disc_forward': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    'agx_cgan_disc_grads': (C.c_int, [_vp, _vp, C.POINTER(StepArgs)]),
+    'agx_cgan_gen_grads': (C.c_int, [_vp, _vp, C.POINTER(StepArgs)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libagx.so once; raise AgxError (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AgxError('libagx.so not found at %s - build it with `python -c "import __graft_entry__ as g; '
+                       'g.build()"` or `make -C adversarial_gene_expression_amd/csrc`; there is no CPU '
+                       'fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().agx_last_error()
+        raise AgxError('%s failed (code %d): %s' % (what or 'libagx call', rc, (msg or b'').decode()))
+
+
+_initialised = set()
+
+
+def init_device(device_index):
+    """agx_init on first use of a device (verifies gfx950, caches the CU count)."""
+    if device_index not in _initialised:
+        check(load().agx_init(int(device_index)), 'agx_init')
+        _initialised.add(device_index)

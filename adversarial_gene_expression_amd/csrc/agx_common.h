@@ -1,0 +1,57 @@
+// Internal helpers shared by the libagx translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/agx.h"
+
+namespace agx {
+
+void set_error(const char *fmt, ...);
+int num_cus();
+
+#define AGX_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      agx::set_error(__VA_ARGS__);      \
+      return AGX_E_INVALID;             \
+    }                                   \
+  } while (0)
+
+#define AGX_HIP(call)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      agx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                    \
+      return AGX_E_HIP;                                                            \
+    }                                                                              \
+  } while (0)
+
+#define AGX_LAUNCH_CHECK() AGX_HIP(hipGetLastError())
+
+#define AGX_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != AGX_OK) return rc_; \
+  } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace agx

@@ -1,0 +1,422 @@
+// Host-side orchestration of the WGAN-GP conditional-GAN train step
+// (reference tf_utils.py:186-258).  Pure launch sequencing on one stream: no
+// allocation, no synchronisation, no host<->device copies, so a caller may
+// capture a whole iteration into a hipGraph.
+//
+// The backward pass is hand-derived (no autodiff engine):
+//
+// * The critic is evaluated ONCE on the stacked batch S = [real; fake; inter]
+//   (3B rows).  The first-order chain  D_{l-1} = relu'(A_{l-1}) * (D_l . W_l^T)
+//   is seeded with c (x) w_out^T, c = [-1/B | +1/B | 1]: rows 0..2B carry the
+//   Wasserstein deltas, rows 2B..3B carry d_l of the gradient penalty
+//   (g = d_1 . W_1[:G]^T is the input gradient of tf_utils.py:165-168).
+// * With dg = weight*(2/B)*(s-1)/s * g the penalty's second-order chain
+//   e_l = relu'(A_l) * (e_{l-1} . W_l), e_0 = dg, is written IN PLACE over the
+//   inter rows of the activations (and dg over the inter rows of the input),
+//   so that every weight gradient is one stacked product
+//       dW_l = [a_{l-1}(real); a_{l-1}(fake); e_{l-1}]^T . [D_l]      (K = 3B)
+//   which equals  sum_{real,fake} a^T delta  +  the penalty term e^T d.
+//   The penalty contributes nothing to biases, embeddings or the covariate
+//   rows of W_1 (ReLU masks are piecewise constant): the covariate columns of
+//   the inter rows are zeroed before the dW_1 product and bias gradients sum
+//   rows 0..2B only.
+#include "agx_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+struct agx_cgan {
+  agx_cgan_config_t cfg;
+  bool bound = false;
+  float *gp = nullptr, *gg = nullptr, *dp = nullptr, *dg = nullptr;  // flat params / grads
+  // workspace views
+  int Bm = 0, G = 0, Dd = 0, Dg = 0, ldx = 0, ldg0 = 0, ldcov = 0, ncov = 0;
+  float *X = nullptr;                       // [3Bm, ldx] stacked critic input (+cov cols)
+  float *A[AGX_MAX_LAYERS + 1] = {};        // critic activations  [3Bm, ldh]
+  float *D[AGX_MAX_LAYERS + 1] = {};        // critic deltas       [3Bm, ldh]
+  int ldh[AGX_MAX_LAYERS + 1] = {};
+  float *out = nullptr, *slopes = nullptr;  // [3Bm], [Bm]
+  float *dcov = nullptr;                    // [2Bm, ldcov]
+  float *gin0 = nullptr, *gdin0 = nullptr;  // [Bm, ldg0]
+  float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [Bm, ldgh]
+  float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas
+  int ldgh[AGX_MAX_LAYERS + 1] = {};
+  float *skws = nullptr;                    // split-K scratch
+  int64_t skws_floats = 0;
+  int64_t ws_floats_total = 0;
+};
+
+namespace {
+
+inline int r4(int x) { return (x + 3) & ~3; }
+inline int64_t r64(int64_t x) { return (x + 63) & ~(int64_t)63; }
+
+int validate_mlp(const agx_mlp_desc_t &m, const char *name, int want_in, int want_out) {
+  AGX_CHECK_ARG(m.n_layers >= 2 && m.n_layers <= AGX_MAX_LAYERS,
+                "%s: n_layers=%d (need >= 1 hidden layer, <= %d layers)", name, m.n_layers,
+                AGX_MAX_LAYERS);
+  AGX_CHECK_ARG(m.emb.n_cat >= 0 && m.emb.n_cat <= AGX_MAX_CAT, "%s: n_cat=%d", name, m.emb.n_cat);
+  int e = 0;
+  for (int i = 0; i < m.emb.n_cat; ++i) {
+    AGX_CHECK_ARG(m.emb.vocab[i] > 0 && m.emb.edim[i] > 0, "%s: bad embedding %d", name, i);
+    AGX_CHECK_ARG(m.emb.table_off[i] >= 0 && m.emb.table_off[i] + (int64_t)m.emb.vocab[i] * m.emb.edim[i] <= m.n_flat,
+                  "%s: embedding %d outside the flat buffer", name, i);
+    e += m.emb.edim[i];
+  }
+  AGX_CHECK_ARG(m.dims[0] == want_in + m.n_num + e, "%s: dims[0]=%d != %d+%d+%d", name, m.dims[0],
+                want_in, m.n_num, e);
+  AGX_CHECK_ARG(m.dims[m.n_layers] == want_out, "%s: output width %d != %d", name,
+                m.dims[m.n_layers], want_out);
+  for (int l = 0; l < m.n_layers; ++l) {
+    AGX_CHECK_ARG(m.dims[l + 1] > 0 && m.ldw[l] >= m.dims[l + 1], "%s: layer %d ldw", name, l);
+    AGX_CHECK_ARG(m.w_off[l] >= 0 && m.w_off[l] % 4 == 0 && m.w_off[l] + (int64_t)m.dims[l] * m.ldw[l] <= m.n_flat,
+                  "%s: kernel %d outside the flat buffer / unaligned", name, l);
+    AGX_CHECK_ARG(m.b_off[l] >= 0 && m.b_off[l] + m.dims[l + 1] <= m.n_flat,
+                  "%s: bias %d outside the flat buffer", name, l);
+  }
+  return AGX_OK;
+}
+
+struct Carver {
+  int64_t off = 0;
+  float *base;
+  explicit Carver(float *b) : base(b) {}
+  float *take(int64_t n) {
+    float *p = base ? base + off : nullptr;
+    off += r64(n);
+    return p;
+  }
+};
+
+void carve(agx_cgan *h, float *base) {
+  const agx_cgan_config_t &c = h->cfg;
+  const int Bm = c.max_batch;
+  Carver cv(base);
+  h->X = cv.take((int64_t)3 * Bm * h->ldx);
+  const int L = c.disc.n_layers - 1;
+  for (int l = 1; l <= L; ++l) {
+    h->ldh[l] = r4(c.disc.dims[l]);
+    h->A[l] = cv.take((int64_t)3 * Bm * h->ldh[l]);
+    h->D[l] = cv.take((int64_t)3 * Bm * h->ldh[l]);
+  }
+  h->out = cv.take(3 * Bm);
+  h->slopes = cv.take(Bm);
+  h->dcov = cv.take((int64_t)2 * Bm * h->ldcov);
+  h->gin0 = cv.take((int64_t)Bm * h->ldg0);
+  h->gdin0 = cv.take((int64_t)Bm * h->ldg0);
+  const int Lg = c.gen.n_layers - 1;
+  for (int l = 1; l <= Lg; ++l) {
+    h->ldgh[l] = r4(c.gen.dims[l]);
+    h->gh[l] = cv.take((int64_t)Bm * h->ldgh[l]);
+    h->gd[l] = cv.take((int64_t)Bm * h->ldgh[l]);
+  }
+  // split-K scratch: the largest request over the GEMM shapes of both steps
+  int64_t need = 0;
+  const int Bs[2] = {Bm, std::min(Bm, 32)};
+  for (int bi = 0; bi < 2; ++bi) {
+    const int B = Bs[bi];
+    for (int l = 0; l < c.disc.n_layers - 1; ++l) {
+      need = std::max(need, agx_gemm_ws_floats(3 * B, c.disc.dims[l + 1], c.disc.dims[l]));
+      need = std::max(need, agx_gemm_ws_floats(B, c.disc.dims[l + 1], c.disc.dims[l]));
+      need = std::max(need, agx_gemm_ws_floats(3 * B, c.disc.dims[l], c.disc.dims[l + 1]));
+      need = std::max(need, agx_gemm_ws_floats(B, c.disc.dims[l], c.disc.dims[l + 1]));
+      need = std::max(need, agx_gemm_ws_floats(c.disc.dims[l], c.disc.dims[l + 1], 3 * B));
+    }
+    for (int l = 0; l < c.gen.n_layers; ++l) {
+      need = std::max(need, agx_gemm_ws_floats(B, c.gen.dims[l + 1], c.gen.dims[l]));
+      need = std::max(need, agx_gemm_ws_floats(B, c.gen.dims[l], c.gen.dims[l + 1]));
+      need = std::max(need, agx_gemm_ws_floats(c.gen.dims[l], c.gen.dims[l + 1], B));
+    }
+  }
+  h->skws_floats = r64(need);
+  h->skws = cv.take(h->skws_floats);
+  h->ws_floats_total = cv.off;
+}
+
+struct Gemm {  // GEMM call builder
+  agx_gemm_t g;
+  Gemm(agx_cgan *h, const float *A, int lda, int ta, const float *B, int ldb, int tb, float *C, int ldc,
+    int M, int N, int K) {
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.ta = ta; g.tb = tb;
+    g.alpha = 1.f;
+    g.slope = h->cfg.slope;
+    g.ws = h->skws;
+    g.ws_floats = h->skws_floats;
+    g.force_cfg = -1;
+    g.force_splitk = 0;
+  }
+  Gemm &bias(const float *b) { g.bias = b; return *this; }
+  Gemm &act() { g.act = 1; return *this; }
+  Gemm &mask(const float *m, int ld) { g.mask = m; g.ldmask = ld; return *this; }
+  int run(hipStream_t st) { return agx_gemm_f32(st, &g); }
+};
+
+// generator forward; activations kept in h->gh[]; output [B, x_dim] into (out, ldo)
+int gen_forward(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, const float *num,
+                int B, float *out, int ldo) {
+  const agx_mlp_desc_t &m = h->cfg.gen;
+  AGX_TRY(agx_embed_concat_fwd(st, &m.emb, h->gp, z, h->cfg.z_dim, h->cfg.z_dim, num, m.n_num,
+                               m.n_num, cat, m.emb.n_cat, B, 0, h->gin0, h->ldg0));
+  const float *in = h->gin0;
+  int ldin = h->ldg0;
+  for (int l = 0; l < m.n_layers; ++l) {
+    const bool last = (l == m.n_layers - 1);
+    float *o = last ? out : h->gh[l + 1];
+    const int ldo_l = last ? ldo : h->ldgh[l + 1];
+    Gemm g(h, in, ldin, 0, h->gp + m.w_off[l], m.ldw[l], 0, o, ldo_l, B, m.dims[l + 1], m.dims[l]);
+    g.bias(h->gp + m.b_off[l]);
+    if (!last) g.act();
+    AGX_TRY(g.run(st));
+    in = o;
+    ldin = ldo_l;
+  }
+  return AGX_OK;
+}
+
+// critic forward over R rows of h->X (gene columns already in place); fills covariate
+// columns (source rows modulo B), activations A[1..L] and scores out[R]
+int disc_forward_rows(agx_cgan *h, hipStream_t st, const int32_t *cat, const float *num, int R,
+                      int B) {
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  const int L = m.n_layers - 1;
+  AGX_TRY(agx_embed_concat_fwd(st, &m.emb, h->dp, nullptr, 0, 0, num, m.n_num, m.n_num, cat,
+                               m.emb.n_cat, R, B, h->X + h->G, h->ldx));
+  const float *in = h->X;
+  int ldin = h->ldx;
+  for (int l = 0; l < L; ++l) {
+    Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, h->A[l + 1], h->ldh[l + 1], R,
+        m.dims[l + 1], m.dims[l]);
+    g.bias(h->dp + m.b_off[l]).act();
+    AGX_TRY(g.run(st));
+    in = h->A[l + 1];
+    ldin = h->ldh[l + 1];
+  }
+  return agx_rowdot(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->dp + m.b_off[L], h->out, R,
+                    m.dims[L]);
+}
+
+// first-order chain D[L] -> D[1] over R rows
+int disc_backward_chain(agx_cgan *h, hipStream_t st, int R) {
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  const int L = m.n_layers - 1;
+  for (int l = L; l >= 2; --l) {
+    // D[l-1] = act'(A[l-1]) * (D[l] . W_{l-1}^T);  W_{l-1}: [d_{l-1}, d_l]
+    Gemm g(h, h->D[l], h->ldh[l], 0, h->dp + m.w_off[l - 1], m.ldw[l - 1], 1, h->D[l - 1],
+        h->ldh[l - 1], R, m.dims[l - 1], m.dims[l]);
+    g.mask(h->A[l - 1], h->ldh[l - 1]);
+    AGX_TRY(g.run(st));
+  }
+  return AGX_OK;
+}
+
+int check_step(const agx_cgan *h, const agx_step_args_t *a, bool critic) {
+  AGX_CHECK_ARG(h && a, "null handle/args");
+  if (!h->bound) {
+    agx::set_error("agx_cgan: workspace/params not bound");
+    return AGX_E_STATE;
+  }
+  AGX_CHECK_ARG(a->B > 0 && a->B <= h->Bm, "batch %d outside (0, max_batch=%d]", a->B, h->Bm);
+  AGX_CHECK_ARG(a->B_global >= a->B, "B_global %d < B %d", a->B_global, a->B);
+  AGX_CHECK_ARG(a->z && a->losses, "z / losses missing");
+  AGX_CHECK_ARG(h->cfg.gen.emb.n_cat == 0 || a->cat, "cat missing");
+  AGX_CHECK_ARG(h->cfg.gen.n_num == 0 || a->num, "num missing");
+  if (critic) {
+    AGX_CHECK_ARG(a->x && a->ldx >= h->G && a->alpha, "x / alpha missing or ldx < x_dim");
+    AGX_CHECK_ARG(!a->aug_mask || (a->aug_noise_fake && a->aug_noise_real), "aug noise missing");
+  } else {
+    AGX_CHECK_ARG(!a->aug_mask || a->aug_noise_fake, "aug noise missing");
+  }
+  return AGX_OK;
+}
+
+}  // namespace
+
+extern "C" int agx_cgan_create(const agx_cgan_config_t *cfg, agx_cgan_t **out) {
+  AGX_CHECK_ARG(cfg && out, "agx_cgan_create: null argument");
+  AGX_CHECK_ARG(cfg->x_dim > 0 && cfg->z_dim > 0 && cfg->max_batch > 0, "agx_cgan_create: bad dims");
+  AGX_CHECK_ARG(cfg->slope >= 0.f && cfg->slope < 1.f, "agx_cgan_create: slope must be in [0,1)");
+  AGX_TRY(validate_mlp(cfg->gen, "generator", cfg->z_dim, cfg->x_dim));
+  AGX_TRY(validate_mlp(cfg->disc, "critic", cfg->x_dim, 1));
+  AGX_CHECK_ARG(cfg->disc.ldw[cfg->disc.n_layers - 1] == 1, "critic output kernel must have ldw == 1");
+  AGX_CHECK_ARG(cfg->gen.n_num == cfg->disc.n_num && cfg->gen.emb.n_cat == cfg->disc.emb.n_cat,
+                "generator and critic must share the covariate layout");
+  agx_cgan *h = new (std::nothrow) agx_cgan();
+  AGX_CHECK_ARG(h, "agx_cgan_create: out of host memory");
+  h->cfg = *cfg;
+  h->Bm = cfg->max_batch;
+  h->G = cfg->x_dim;
+  h->Dd = cfg->disc.dims[0];
+  h->Dg = cfg->gen.dims[0];
+  h->ldx = r4(h->Dd);
+  h->ldg0 = r4(h->Dg);
+  h->ncov = h->Dd - h->G;
+  h->ldcov = r4(std::max(h->ncov, 1));
+  carve(h, nullptr);
+  *out = h;
+  return AGX_OK;
+}
+
+extern "C" int agx_cgan_destroy(agx_cgan_t *h) {
+  delete h;
+  return AGX_OK;
+}
+
+extern "C" int64_t agx_cgan_workspace_bytes(const agx_cgan_t *h) {
+  return h ? h->ws_floats_total * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int agx_cgan_bind(agx_cgan_t *h, float *gen_params, float *gen_grads, float *disc_params,
+                             float *disc_grads, void *workspace, int64_t workspace_bytes) {
+  AGX_CHECK_ARG(h && gen_params && gen_grads && disc_params && disc_grads && workspace,
+                "agx_cgan_bind: null argument");
+  AGX_CHECK_ARG(agx::aligned16(gen_params) && agx::aligned16(gen_grads) && agx::aligned16(disc_params) &&
+                    agx::aligned16(disc_grads) && agx::aligned16(workspace),
+                "agx_cgan_bind: buffers must be 16-byte aligned");
+  if (workspace_bytes < agx_cgan_workspace_bytes(h)) {
+    agx::set_error("agx_cgan_bind: workspace %lld B < required %lld B", (long long)workspace_bytes,
+                   (long long)agx_cgan_workspace_bytes(h));
+    return AGX_E_WORKSPACE;
+  }
+  h->gp = gen_params; h->gg = gen_grads; h->dp = disc_params; h->dg = disc_grads;
+  carve(h, static_cast<float *>(workspace));
+  h->bound = true;
+  return AGX_OK;
+}
+
+extern "C" int agx_cgan_gen_forward(agx_cgan_t *h, void *stream, const float *z, const int32_t *cat,
+                                    const float *num, int32_t B, float *out, int32_t ldo) {
+  AGX_CHECK_ARG(h && z && out, "agx_cgan_gen_forward: null argument");
+  if (!h->bound) { agx::set_error("agx_cgan_gen_forward: not bound"); return AGX_E_STATE; }
+  AGX_CHECK_ARG(B > 0 && B <= h->Bm && ldo >= h->G, "agx_cgan_gen_forward: bad B=%d / ldo=%d", B, ldo);
+  return gen_forward(h, agx::as_stream(stream), z, cat, num, B, out, ldo);
+}
+
+extern "C" int agx_cgan_disc_forward(agx_cgan_t *h, void *stream, const float *x, int32_t ldx,
+                                     const int32_t *cat, const float *num, int32_t B, float *scores) {
+  AGX_CHECK_ARG(h && x && scores, "agx_cgan_disc_forward: null argument");
+  if (!h->bound) { agx::set_error("agx_cgan_disc_forward: not bound"); return AGX_E_STATE; }
+  AGX_CHECK_ARG(B > 0 && B <= 3 * h->Bm && ldx >= h->G, "agx_cgan_disc_forward: bad B / ldx");
+  hipStream_t st = agx::as_stream(stream);
+  AGX_HIP(hipMemcpy2DAsync(h->X, (size_t)h->ldx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
+                           hipMemcpyDeviceToDevice, st));
+  AGX_TRY(disc_forward_rows(h, st, cat, num, B, 0));
+  AGX_HIP(hipMemcpyAsync(scores, h->out, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  return AGX_OK;
+}
+
+extern "C" int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a) {
+  AGX_TRY(check_step(h, a, true));
+  hipStream_t st = agx::as_stream(stream);
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  const int L = m.n_layers - 1, B = a->B, R = 3 * B, G = h->G, ldx = h->ldx;
+  const float invb = 1.0f / (float)a->B_global;
+  float *Xr = h->X, *Xf = h->X + (size_t)B * ldx, *Xi = h->X + (size_t)2 * B * ldx;
+
+  // fake batch straight into rows B..2B (generator is not differentiated, tf_utils.py:206)
+  AGX_TRY(gen_forward(h, st, a->z, a->cat, a->num, B, Xf, ldx));
+  AGX_HIP(hipMemcpy2DAsync(Xr, (size_t)ldx * 4, a->x, (size_t)a->ldx * 4, (size_t)G * 4, B,
+                           hipMemcpyDeviceToDevice, st));
+  if (a->aug_mask) {  // tf_utils.py:209-210
+    AGX_TRY(agx_aug_add(st, Xf, ldx, a->aug_mask, a->aug_noise_fake, G, 1, B, G));
+    AGX_TRY(agx_aug_add(st, Xr, ldx, a->aug_mask, a->aug_noise_real, G, 0, B, G));
+  }
+  AGX_TRY(agx_gp_interp(st, Xr, ldx, Xf, ldx, a->alpha, Xi, ldx, B, G));  // :162-164
+  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, R, B));                // :213-214, :167
+
+  // seed + first-order chain
+  AGX_TRY(agx_delta_init(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->D[L], h->ldh[L], R,
+                         m.dims[L], B, B, -invb, invb, 1.f, h->cfg.slope));
+  AGX_TRY(disc_backward_chain(h, st, R));
+  // g = d_1 . W_1[:G]^T  -> inter rows of X (inter itself is dead now)      :168
+  AGX_TRY(Gemm(h, h->D[1] + (size_t)2 * B * h->ldh[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1,
+            Xi, ldx, B, G, m.dims[1]).run(st));
+  // slopes, gp, dg = weight*(2/B)*(s-1)/s * g                                :169-170
+  AGX_TRY(agx_gp_rownorm_scale(st, Xi, ldx, h->slopes, B, G, a->gp_weight * 2.0f * invb));
+  AGX_TRY(agx_wgan_loss(st, h->out, B, B, h->slopes, B, invb, a->gp_weight, 1.f, a->losses));
+  if (h->ncov > 0)  // the penalty has no gradient w.r.t. the covariate rows of W_1
+    AGX_HIP(hipMemset2DAsync(Xi + G, (size_t)ldx * 4, 0, (size_t)h->ncov * 4, B, st));
+
+  // second-order chain, in place over the inter rows of the activations
+  {
+    const float *in = Xi;
+    int ldin = ldx, K = G;
+    for (int l = 0; l < L; ++l) {
+      float *Ai = h->A[l + 1] + (size_t)2 * B * h->ldh[l + 1];
+      Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, Ai, h->ldh[l + 1], B, m.dims[l + 1], K);
+      g.mask(Ai, h->ldh[l + 1]);
+      AGX_TRY(g.run(st));
+      in = Ai;
+      ldin = h->ldh[l + 1];
+      K = m.dims[l + 1];
+    }
+  }
+
+  // gradients.  Dense(1): dw = sum_r c(r) A'_L[r,:], db = sum c
+  AGX_TRY(agx_colsum_weighted(st, h->A[L], h->ldh[L], R, m.dims[L], B, B, -invb, invb, 1.f,
+                              h->dg + m.w_off[L], h->dg + m.b_off[L]));
+  for (int l = L - 1; l >= 0; --l) {
+    const float *in = l == 0 ? h->X : h->A[l];
+    const int ldin = l == 0 ? ldx : h->ldh[l];
+    AGX_TRY(Gemm(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l],
+              m.dims[l], m.dims[l + 1], R).run(st));
+    AGX_TRY(agx_colsum(st, h->D[l + 1], h->ldh[l + 1], 0, 2 * B, m.dims[l + 1], h->dg + m.b_off[l], 0));
+  }
+  if (m.emb.n_cat > 0) {
+    // d cov = D_1[0:2B] . W_1[G:, :]^T ; scatter-add into the tables
+    AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0] + (size_t)G * m.ldw[0], m.ldw[0], 1,
+              h->dcov, h->ldcov, 2 * B, h->ncov, m.dims[1]).run(st));
+    AGX_TRY(agx_embed_bwd(st, &m.emb, h->dg, h->dcov, h->ldcov, m.n_num, a->cat, m.emb.n_cat, 2 * B,
+                          B, 0));
+  }
+  return AGX_OK;
+}
+
+extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a) {
+  AGX_TRY(check_step(h, a, false));
+  hipStream_t st = agx::as_stream(stream);
+  const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
+  const int L = m.n_layers - 1, Lg = gm.n_layers - 1, B = a->B, G = h->G, ldx = h->ldx;
+  const float invb = 1.0f / (float)a->B_global;
+  float *Xg = h->X, *dX = h->X + (size_t)B * ldx;
+
+  AGX_TRY(gen_forward(h, st, a->z, a->cat, a->num, B, Xg, ldx));                    // :244
+  if (a->aug_mask) AGX_TRY(agx_aug_add(st, Xg, ldx, a->aug_mask, a->aug_noise_fake, G, 0, B, G));  // :247
+  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, B, 0));                          // :250
+  AGX_TRY(agx_wgan_loss(st, h->out, B, 0, nullptr, 0, invb, 0.f, 1.f, a->losses));  // :253
+  // back through the critic to its input (critic weights untouched)               :255
+  AGX_TRY(agx_delta_init(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->D[L], h->ldh[L], B,
+                         m.dims[L], B, 0, -invb, 0.f, 0.f, h->cfg.slope));
+  AGX_TRY(disc_backward_chain(h, st, B));
+  AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1]).run(st));
+
+  // generator backward
+  const float *dout = dX;
+  int lddout = ldx;
+  for (int l = Lg; l >= 0; --l) {
+    const float *in = l == 0 ? h->gin0 : h->gh[l];
+    const int ldin = l == 0 ? h->ldg0 : h->ldgh[l];
+    AGX_TRY(Gemm(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l],
+              gm.dims[l + 1], B).run(st));
+    AGX_TRY(agx_colsum(st, dout, lddout, 0, B, gm.dims[l + 1], h->gg + gm.b_off[l], 0));
+    if (l > 0) {
+      Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
+          gm.dims[l + 1]);
+      g.mask(h->gh[l], h->ldgh[l]);
+      AGX_TRY(g.run(st));
+      dout = h->gd[l];
+      lddout = h->ldgh[l];
+    } else if (gm.emb.n_cat > 0) {
+      AGX_TRY(Gemm(h, dout, lddout, 0, h->gp + gm.w_off[0], gm.ldw[0], 1, h->gdin0, h->ldg0, B,
+                gm.dims[0], gm.dims[1]).run(st));
+      AGX_TRY(agx_embed_bwd(st, &gm.emb, h->gg, h->gdin0, h->ldg0, h->cfg.z_dim + gm.n_num, a->cat,
+                            gm.emb.n_cat, B, 0, 0));
+    }
+  }
+  return AGX_OK;
+}

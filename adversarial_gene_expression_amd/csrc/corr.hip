@@ -1,0 +1,267 @@
+// HBM-bound kernels of the correlation / gamma evaluation path
+// (reference utils.py:260-268, 808-873): column statistics, standardisation,
+// condensed upper-triangle packing with the reference's NaN-dropping, and the
+// five-sum reduction behind the final 1-D Pearson.  The G x G contraction
+// itself is agx_corr_xtx in gemm.hip.
+#include "agx_common.h"
+
+namespace {
+
+using agx::wave_sum;
+
+// blockDim 256 = 64 columns x 4 row phases; grid (ceil(G/64), row chunks)
+__global__ void __launch_bounds__(256) colstats_partial_kernel(const float *__restrict__ x, int ldx,
+                                                               int N, int G, int rows_per_chunk,
+                                                               double *__restrict__ ws) {
+  __shared__ double red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int rbeg = blockIdx.y * rows_per_chunk;
+  const int rend = min(N, rbeg + rows_per_chunk);
+  double s = 0.0, q = 0.0;
+  if (c < G) {
+    for (int r = rbeg + ty; r < rend; r += 4) {
+      const double v = (double)x[(size_t)r * ldx + c];
+      s += v;
+      q += v * v;
+    }
+  }
+  red[0][ty][tx] = s;
+  red[1][ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && c < G) {
+    s = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+    q = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    atomicAdd(ws + c, s);
+    atomicAdd(ws + G + c, q);
+  }
+}
+
+__global__ void __launch_bounds__(256) colstats_finish_kernel(const double *__restrict__ ws, int N,
+                                                              int G, float *__restrict__ mean,
+                                                              float *__restrict__ stdv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= G) return;
+  const double m = ws[c] / (double)N;
+  double var = ws[G + c] / (double)N - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  stdv[c] = (float)sqrt(var);
+}
+
+__global__ void __launch_bounds__(256) standardize_kernel(const float *__restrict__ x, int ldx,
+                                                          int G, const float *__restrict__ mean,
+                                                          const float *__restrict__ stdv,
+                                                          float *__restrict__ out, int ldo) {
+  const int r = blockIdx.y;
+  const float *xr = x + (size_t)r * ldx;
+  float *orow = out + (size_t)r * ldo;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < G; c += gridDim.x * blockDim.x)
+    orow[c] = (xr[c] - mean[c]) / stdv[c];  // x/0 -> inf/NaN exactly as NumPy
+}
+
+// ---- condensed upper triangle with NaN dropping ---------------------------
+__global__ void __launch_bounds__(256) triu_count_kernel(const float *__restrict__ C, int ldc, int G,
+                                                         long long *__restrict__ counts) {
+  __shared__ int red[4];
+  const int i = blockIdx.x;
+  const float *row = C + (size_t)i * ldc;
+  int n = 0;
+  for (int j = i + 1 + threadIdx.x; j < G; j += blockDim.x) n += !isnan(row[j]);
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[i] = red[0] + red[1] + red[2] + red[3];
+}
+
+// single block exclusive scan of counts[0..G) -> offsets[0..G]; offsets[G] = total
+__global__ void __launch_bounds__(1024) scan_kernel(const long long *__restrict__ counts, int G,
+                                                    long long *__restrict__ offsets,
+                                                    long long *__restrict__ total) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const int per = (G + 1023) / 1024;
+  const int beg = t * per, end = min(G, beg + per);
+  long long s = 0;
+  for (int i = beg; i < end; ++i) s += counts[i];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    long long run = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const long long v = part[k];
+      part[k] = run;
+      run += v;
+    }
+    offsets[G] = run;
+    if (total) *total = run;
+  }
+  __syncthreads();
+  long long run = part[t];
+  for (int i = beg; i < end; ++i) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+}
+
+__global__ void __launch_bounds__(256) triu_write_kernel(const float *__restrict__ C, int ldc, int G,
+                                                         const long long *__restrict__ offsets,
+                                                         float *__restrict__ out) {
+  __shared__ int wtot[4];
+  const int i = blockIdx.x;
+  const float *row = C + (size_t)i * ldc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long base = offsets[i];
+  for (int j0 = i + 1; j0 < G; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    float v = 0.f;
+    bool keep = false;
+    if (j < G) {
+      v = row[j];
+      keep = !isnan(v);
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wtot[w];
+    const int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (keep) out[base + wbase + before] = v;
+    base += tot;
+    __syncthreads();
+  }
+}
+
+// ---- five sums for the 1-D Pearson ----------------------------------------
+__device__ __forceinline__ void block_add5(double (&s)[6], int nvals, double *__restrict__ sums) {
+  __shared__ double red[6][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (k < nvals) {
+      const double v = wave_sum(s[k]);
+      if (lane == 0) red[k][wave] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nvals) {
+    const int k = threadIdx.x;
+    atomicAdd(sums + k, red[k][0] + red[k][1] + red[k][2] + red[k][3]);
+  }
+}
+
+__global__ void __launch_bounds__(256) pearson_sums_kernel(const float *__restrict__ a,
+                                                           const float *__restrict__ b, long long n,
+                                                           int one_minus,
+                                                           double *__restrict__ sums) {
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float fa = a[i], fb = b[i];
+    if (one_minus) {
+      fa = 1.0f - fa;  // utils.py:870-871 (fp32 subtraction)
+      fb = 1.0f - fb;
+    }
+    const double da = fa, db = fb;
+    s[0] += da; s[1] += db; s[2] += da * da; s[3] += db * db; s[4] += da * db;
+  }
+  block_add5(s, 5, sums);
+}
+
+__global__ void __launch_bounds__(256) gamma_sums_kernel(const float *__restrict__ C1, int ld1,
+                                                         const float *__restrict__ C2, int ld2,
+                                                         int G, double *__restrict__ sums) {
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x; i < G; i += gridDim.x) {
+    const float *r1 = C1 + (size_t)i * ld1;
+    const float *r2 = C2 + (size_t)i * ld2;
+    for (int j = i + 1 + threadIdx.x; j < G; j += blockDim.x) {
+      const float fa = 1.0f - r1[j], fb = 1.0f - r2[j];
+      if (isnan(fa) || isnan(fb)) {
+        s[5] += 1.0;
+      } else {
+        const double da = fa, db = fb;
+        s[0] += da; s[1] += db; s[2] += da * da; s[3] += db * db; s[4] += da * db;
+      }
+    }
+  }
+  block_add5(s, 6, sums);
+}
+
+}  // namespace
+
+extern "C" int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
+                            float *mean, float *std, double *ws) {
+  AGX_CHECK_ARG(x && mean && std && ws, "agx_colstats: null argument");
+  AGX_CHECK_ARG(N > 0 && G > 0 && ldx >= G, "agx_colstats: bad shape N=%d G=%d ldx=%d", N, G, ldx);
+  hipStream_t st = agx::as_stream(stream);
+  AGX_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)G, st));
+  const int gx = agx::cdiv(G, 64);
+  int chunks = std::max(1, std::min(agx::cdiv(N, 64), agx::cdiv(4 * agx::num_cus(), gx)));
+  const int rpc = agx::cdiv(N, chunks);
+  chunks = agx::cdiv(N, rpc);
+  hipLaunchKernelGGL(colstats_partial_kernel, dim3(gx, chunks), dim3(256), 0, st, x, ldx, N, G, rpc,
+                     ws);
+  AGX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colstats_finish_kernel, dim3(agx::cdiv(G, 256)), dim3(256), 0, st, ws, N, G,
+                     mean, std);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_standardize(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
+                               const float *mean, const float *std, float *out, int32_t ldo) {
+  AGX_CHECK_ARG(x && mean && std && out, "agx_standardize: null argument");
+  AGX_CHECK_ARG(N >= 0 && G > 0 && ldx >= G && ldo >= G, "agx_standardize: bad shape");
+  if (N == 0) return AGX_OK;
+  AGX_CHECK_ARG(N <= 65535 * 16, "agx_standardize: N too large for one launch");
+  hipStream_t st = agx::as_stream(stream);
+  for (int r0 = 0; r0 < N; r0 += 65535) {  // gridDim.y limit
+    const int rows = std::min(65535, N - r0);
+    hipLaunchKernelGGL(standardize_kernel, dim3(std::min(agx::cdiv(G, 256), 32), rows), dim3(256),
+                       0, st, x + (size_t)r0 * ldx, ldx, G, mean, std, out + (size_t)r0 * ldo, ldo);
+    AGX_LAUNCH_CHECK();
+  }
+  return AGX_OK;
+}
+
+extern "C" int agx_triu_pack(void *stream, const float *C, int32_t ldc, int32_t G, float *out,
+                             int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev) {
+  AGX_CHECK_ARG(C && out && row_counts && row_offsets, "agx_triu_pack: null argument");
+  AGX_CHECK_ARG(G > 0 && ldc >= G, "agx_triu_pack: bad shape");
+  hipStream_t st = agx::as_stream(stream);
+  hipLaunchKernelGGL(triu_count_kernel, dim3(G), dim3(256), 0, st, C, ldc, G,
+                     reinterpret_cast<long long *>(row_counts));
+  AGX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st,
+                     reinterpret_cast<const long long *>(row_counts), G,
+                     reinterpret_cast<long long *>(row_offsets),
+                     reinterpret_cast<long long *>(n_out_dev));
+  AGX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(triu_write_kernel, dim3(G), dim3(256), 0, st, C, ldc, G,
+                     reinterpret_cast<const long long *>(row_offsets), out);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_pearson_sums(void *stream, const float *a, const float *b, int64_t n,
+                                int32_t one_minus, double *sums) {
+  AGX_CHECK_ARG(a && b && sums && n >= 0, "agx_pearson_sums: bad argument");
+  if (n == 0) return AGX_OK;
+  int blocks = (int)std::min<int64_t>(agx::cdiv64(n, 256 * 8), 2048);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pearson_sums_kernel, dim3(blocks), dim3(256), 0, agx::as_stream(stream), a, b,
+                     (long long)n, one_minus, sums);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const float *C2,
+                              int32_t ld2, int32_t G, double *sums) {
+  AGX_CHECK_ARG(C1 && C2 && sums && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums: bad argument");
+  hipLaunchKernelGGL(gamma_sums_kernel, dim3(std::min(G, 2048)), dim3(256), 0,
+                     agx::as_stream(stream), C1, ld1, C2, ld2, G, sums);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}

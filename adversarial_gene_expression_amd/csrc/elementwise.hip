@@ -1,0 +1,504 @@
+// HBM-bound kernels of the cGAN train step: embedding gather/concat and its
+// scatter-add gradient, WGAN-GP loss pieces, bias-gradient reductions, fused
+// optimizers, Philox RNG.  Reference lines are cited per entry point in
+// include/agx.h.
+#include "agx_common.h"
+
+namespace {
+
+using agx::wave_sum;
+
+// ---------------------------------------------------------------------------
+// embeddings
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) embed_concat_fwd_kernel(
+    agx_embed_t e, const float *__restrict__ tables, const float *__restrict__ lead, int n_lead,
+    int ld_lead, const float *__restrict__ num, int n_num, int ld_num,
+    const int *__restrict__ cat, int ld_cat, int B, int row_mod, float *__restrict__ out, int ldo,
+    int width) {
+  const long long total = (long long)B * width;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ob = (int)(idx / width);
+    const int b = row_mod > 0 ? ob % row_mod : ob;
+    int c = (int)(idx % width);
+    float v = 0.f;
+    if (c < n_lead) {
+      v = lead[(size_t)b * ld_lead + c];
+    } else if (c < n_lead + n_num) {
+      v = num[(size_t)b * ld_num + (c - n_lead)];
+    } else {
+      c -= n_lead + n_num;
+      for (int i = 0; i < e.n_cat; ++i) {
+        if (c < e.edim[i]) {
+          const int row = cat[(size_t)b * ld_cat + i];
+          if (row >= 0 && row < e.vocab[i]) v = tables[e.table_off[i] + (size_t)row * e.edim[i] + c];
+          break;
+        }
+        c -= e.edim[i];
+      }
+    }
+    out[(size_t)ob * ldo + (int)(idx % width)] = v;
+  }
+}
+
+// one block per table row (i, v); waves stride over the embedding columns,
+// lanes over the batch; fixed summation order => deterministic
+__global__ void __launch_bounds__(256) embed_bwd_kernel(agx_embed_t e, float *__restrict__ grad,
+                                                        const float *__restrict__ dout, int ldd,
+                                                        int col0, const int *__restrict__ cat,
+                                                        int ld_cat, int B, int row_mod,
+                                                        int accumulate) {
+  int rowid = blockIdx.x, i = 0, coff = col0;
+  while (i < e.n_cat && rowid >= e.vocab[i]) {
+    rowid -= e.vocab[i];
+    coff += e.edim[i];
+    ++i;
+  }
+  if (i >= e.n_cat) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int d = wave; d < e.edim[i]; d += 4) {
+    float s = 0.f;
+    for (int b = lane; b < B; b += 64) {
+      const int sb = row_mod > 0 ? b % row_mod : b;
+      if (cat[(size_t)sb * ld_cat + i] == rowid) s += dout[(size_t)b * ldd + coff + d];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      float *g = grad + e.table_off[i] + (size_t)rowid * e.edim[i] + d;
+      *g = accumulate ? *g + s : s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// WGAN-GP elementwise pieces
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gp_interp_kernel(const float *__restrict__ real, int ldr,
+                                                        const float *__restrict__ fake, int ldf,
+                                                        const float *__restrict__ alpha,
+                                                        float *__restrict__ inter, int ldi, int B,
+                                                        int G) {
+  const int b = blockIdx.y;
+  const float a = alpha[b];
+  const float *r = real + (size_t)b * ldr;
+  const float *f = fake + (size_t)b * ldf;
+  float *o = inter + (size_t)b * ldi;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
+    const float rv = r[g];
+    const float diff = f[g] - rv;  // tf_utils.py:163
+    o[g] = rv + a * diff;          // tf_utils.py:164 (mul then add, no fma contraction)
+  }
+}
+
+__global__ void __launch_bounds__(256) aug_add_kernel(float *__restrict__ x, int ldx,
+                                                      const float *__restrict__ mask,
+                                                      const float *__restrict__ noise, int ldn,
+                                                      int row_bcast, int B, int G) {
+  const int b = blockIdx.y;
+  const float m = mask[b];
+  const float *n = noise + (row_bcast ? 0 : (size_t)b * ldn);
+  float *o = x + (size_t)b * ldx;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x)
+    o[g] = o[g] + m * n[g];
+}
+
+// one wave per row
+__global__ void __launch_bounds__(256) rowdot_kernel(const float *__restrict__ A, int lda,
+                                                     const float *__restrict__ w,
+                                                     const float *__restrict__ b,
+                                                     float *__restrict__ out, int R, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float *a = A + (size_t)row * lda;
+  float s = 0.f;
+  for (int j = lane; j < H; j += 64) s += a[j] * w[j];
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s + (b ? b[0] : 0.f);
+}
+
+__global__ void __launch_bounds__(256) delta_init_kernel(const float *__restrict__ A, int lda,
+                                                         const float *__restrict__ w,
+                                                         float *__restrict__ delta, int ldd, int R,
+                                                         int H, int n0, int n1, float c0, float c1,
+                                                         float c2, float slope) {
+  const long long total = (long long)R * H;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / H), j = (int)(idx % H);
+    const float c = r < n0 ? c0 : (r < n0 + n1 ? c1 : c2);
+    const float a = A[(size_t)r * lda + j];
+    const float v = c * w[j];
+    delta[(size_t)r * ldd + j] = a > 0.f ? v : v * slope;
+  }
+}
+
+// one block per row: s = ||g||_2 ; g *= coef*(s-1)/s
+__global__ void __launch_bounds__(256) gp_rownorm_scale_kernel(float *__restrict__ g, int ldg,
+                                                               float *__restrict__ slopes, int G,
+                                                               float coef) {
+  __shared__ float red[4];
+  float *row = g + (size_t)blockIdx.x * ldg;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < G; j += blockDim.x) {
+    const float v = row[j];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float tot = red[0] + red[1] + red[2] + red[3];
+  const float sl = sqrtf(tot);  // no epsilon (tf_utils.py:169)
+  if (threadIdx.x == 0) slopes[blockIdx.x] = sl;
+  const float f = coef * (sl - 1.f) / sl;  // sl == 0 -> -inf ; -inf * 0 = NaN as in the reference
+  for (int j = threadIdx.x; j < G; j += blockDim.x) row[j] = row[j] * f;
+}
+
+__global__ void __launch_bounds__(256) wgan_loss_kernel(const float *__restrict__ out, int n0,
+                                                        int n1, const float *__restrict__ slopes,
+                                                        int ns, float inv_b, float gp_weight,
+                                                        float fake_sign, float *__restrict__ losses) {
+  __shared__ float red[3][4];
+  float sr = 0.f, sf = 0.f, sg = 0.f;
+  for (int i = threadIdx.x; i < n0; i += blockDim.x) sr += out[i];
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) sf += out[n0 + i];
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+    const float d = slopes[i] - 1.f;
+    sg += d * d;
+  }
+  sr = wave_sum(sr);
+  sf = wave_sum(sf);
+  sg = wave_sum(sg);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sr;
+    red[1][threadIdx.x >> 6] = sf;
+    red[2][threadIdx.x >> 6] = sg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float r = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float f = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float g = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    const float w = -r * inv_b + fake_sign * f * inv_b;
+    const float gp = g * inv_b;
+    losses[0] = w;
+    losses[1] = gp;
+    losses[2] = w + gp_weight * gp;
+    losses[3] = 0.f;
+  }
+}
+
+// column sums over a row range: blockDim = (64 columns, 4 row phases)
+__global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ A, int lda, int r0,
+                                                     int r1, int H, float *__restrict__ out,
+                                                     int accumulate, int n0, int n1, float c0,
+                                                     float c1, float c2, int weighted,
+                                                     float *__restrict__ bias_out) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (j < H) {
+    for (int r = r0 + ty; r < r1; r += 4) {
+      float v = A[(size_t)r * lda + j];
+      if (weighted) v *= (r < n0 ? c0 : (r < n0 + n1 ? c1 : c2));
+      s += v;
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < H) {
+    const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    out[j] = accumulate ? out[j] + t : t;
+  }
+  if (weighted && bias_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    // BiasAddGrad of the Dense(1): the two means contribute n0*c0 and n1*c1
+    float t0 = 0.f, t1 = 0.f;
+    for (int r = 0; r < n0; ++r) t0 += c0;
+    for (int r = 0; r < n1; ++r) t1 += c1;
+    bias_out[0] = t0 + t1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// optimizers (Keras-v2 formulas; dense apply == sparse apply on the scatter-added grad)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rmsprop_kernel(float *__restrict__ w,
+                                                      const float *__restrict__ g,
+                                                      float *__restrict__ rms, long long n,
+                                                      float lr, float rho, float eps, float gs) {
+  const long long n4 = n >> 2;
+  const float omr = 1.f - rho;
+  float4 *w4 = reinterpret_cast<float4 *>(w);
+  const float4 *g4 = reinterpret_cast<const float4 *>(g);
+  float4 *r4 = reinterpret_cast<float4 *>(rms);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 wv = w4[i], gv = g4[i], rv = r4[i];
+#define AGX_RMS1(c)                                  \
+  {                                                  \
+    const float gg = gv.c * gs;                      \
+    rv.c = rho * rv.c + omr * (gg * gg);             \
+    wv.c = wv.c - lr * gg / (sqrtf(rv.c) + eps);     \
+  }
+    AGX_RMS1(x) AGX_RMS1(y) AGX_RMS1(z) AGX_RMS1(w)
+#undef AGX_RMS1
+    w4[i] = wv;
+    r4[i] = rv;
+  }
+  const long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float gg = g[i] * gs;
+    const float r = rho * rms[i] + omr * (gg * gg);
+    rms[i] = r;
+    w[i] = w[i] - lr * gg / (sqrtf(r) + eps);
+  }
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ w,
+                                                   const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v,
+                                                   long long n, float lr_t, float b1, float b2,
+                                                   float eps, float gs) {
+  const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float gg = g[i] * gs;
+    const float mi = b1 * m[i] + omb1 * gg;
+    const float vi = b2 * v[i] + omb2 * (gg * gg);
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                              unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(unsigned x) {  // [0,1) with 24 random bits
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+template <bool NORMAL>
+__global__ void __launch_bounds__(256) rng_kernel(float *__restrict__ out, long long n,
+                                                  unsigned long long seed,
+                                                  unsigned long long offset) {
+  // counter block q produces elements 4q .. 4q+3 of the (seed, offset)-keyed stream
+  const long long nq = (n + 3) >> 2;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
+       q += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long ctr = (offset >> 2) + (unsigned long long)q;
+    unsigned r[4];
+    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)(offset & 3u), NORMAL ? 1u : 0u,
+                  (unsigned)seed, (unsigned)(seed >> 32), r);
+    float v[4];
+    if (NORMAL) {
+      // Box-Muller on two pairs; 1-u keeps the log argument in (0,1]
+      const float u0 = 1.0f - u01(r[0]), u1 = u01(r[1]);
+      const float u2 = 1.0f - u01(r[2]), u3 = u01(r[3]);
+      const float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+      float s0, c0, s1, c1;
+      __sincosf(6.28318530717958647692f * u1, &s0, &c0);
+      __sincosf(6.28318530717958647692f * u3, &s1, &c1);
+      v[0] = ra * c0; v[1] = ra * s0; v[2] = rb * c1; v[3] = rb * s1;
+    } else {
+      v[0] = u01(r[0]); v[1] = u01(r[1]); v[2] = u01(r[2]); v[3] = u01(r[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * q + k < n) out[4 * q + k] = v[k];
+  }
+}
+
+inline int grid_for(long long n, int per_block = 256, int cap = 4096) {
+  long long b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int agx_embed_concat_fwd(void *stream, const agx_embed_t *e, const float *tables,
+                                    const float *lead, int32_t n_lead, int32_t ld_lead,
+                                    const float *num, int32_t n_num, int32_t ld_num,
+                                    const int32_t *cat, int32_t ld_cat, int32_t B, int32_t row_mod,
+                                    float *out, int32_t ldo) {
+  AGX_CHECK_ARG(e && out, "agx_embed_concat_fwd: null argument");
+  AGX_CHECK_ARG(e->n_cat >= 0 && e->n_cat <= AGX_MAX_CAT, "agx_embed_concat_fwd: n_cat %d", e->n_cat);
+  AGX_CHECK_ARG(n_lead == 0 || lead, "agx_embed_concat_fwd: lead missing");
+  AGX_CHECK_ARG(n_num == 0 || num, "agx_embed_concat_fwd: num missing");
+  AGX_CHECK_ARG(e->n_cat == 0 || (cat && tables && ld_cat >= e->n_cat), "agx_embed_concat_fwd: cat/tables missing");
+  int width = n_lead + n_num;
+  for (int i = 0; i < e->n_cat; ++i) width += e->edim[i];
+  AGX_CHECK_ARG(ldo >= width, "agx_embed_concat_fwd: ldo %d < width %d", ldo, width);
+  if (B <= 0 || width == 0) return AGX_OK;
+  hipLaunchKernelGGL(embed_concat_fwd_kernel, dim3(grid_for((long long)B * width)), dim3(256), 0,
+                     agx::as_stream(stream), *e, tables, lead, n_lead, ld_lead, num, n_num, ld_num,
+                     cat, ld_cat, B, row_mod, out, ldo, width);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_embed_bwd(void *stream, const agx_embed_t *e, float *grad_tables,
+                             const float *dout, int32_t ldd, int32_t col0, const int32_t *cat,
+                             int32_t ld_cat, int32_t B, int32_t row_mod, int32_t accumulate) {
+  AGX_CHECK_ARG(e && e->n_cat >= 0 && e->n_cat <= AGX_MAX_CAT, "agx_embed_bwd: bad descriptor");
+  if (e->n_cat == 0) return AGX_OK;
+  AGX_CHECK_ARG(grad_tables && dout && cat && ld_cat >= e->n_cat, "agx_embed_bwd: null argument");
+  int rows = 0;
+  for (int i = 0; i < e->n_cat; ++i) rows += e->vocab[i];
+  if (rows == 0) return AGX_OK;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(256), 0, agx::as_stream(stream), *e,
+                     grad_tables, dout, ldd, col0, cat, ld_cat, B < 0 ? 0 : B, row_mod, accumulate);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_gp_interp(void *stream, const float *real, int32_t ldr, const float *fake,
+                             int32_t ldf, const float *alpha, float *inter, int32_t ldi, int32_t B,
+                             int32_t G) {
+  AGX_CHECK_ARG(real && fake && alpha && inter, "agx_gp_interp: null argument");
+  AGX_CHECK_ARG(ldr >= G && ldf >= G && ldi >= G, "agx_gp_interp: leading dimension < G");
+  if (B <= 0 || G <= 0) return AGX_OK;
+  hipLaunchKernelGGL(gp_interp_kernel, dim3(std::min(agx::cdiv(G, 256), 64), B), dim3(256), 0,
+                     agx::as_stream(stream), real, ldr, fake, ldf, alpha, inter, ldi, B, G);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_aug_add(void *stream, float *x, int32_t ldx, const float *mask,
+                           const float *noise, int32_t ldn, int32_t row_bcast, int32_t B,
+                           int32_t G) {
+  AGX_CHECK_ARG(x && mask && noise, "agx_aug_add: null argument");
+  AGX_CHECK_ARG(ldx >= G && (row_bcast || ldn >= G), "agx_aug_add: leading dimension < G");
+  if (B <= 0 || G <= 0) return AGX_OK;
+  hipLaunchKernelGGL(aug_add_kernel, dim3(std::min(agx::cdiv(G, 256), 64), B), dim3(256), 0,
+                     agx::as_stream(stream), x, ldx, mask, noise, ldn, row_bcast, B, G);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_rowdot(void *stream, const float *A, int32_t lda, const float *w, const float *b,
+                          float *out, int32_t R, int32_t H) {
+  AGX_CHECK_ARG(A && w && out && lda >= H, "agx_rowdot: bad argument");
+  if (R <= 0) return AGX_OK;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(agx::cdiv(R, 4)), dim3(256), 0, agx::as_stream(stream), A,
+                     lda, w, b, out, R, H);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_delta_init(void *stream, const float *A, int32_t lda, const float *w,
+                              float *delta, int32_t ldd, int32_t R, int32_t H, int32_t n0,
+                              int32_t n1, float c0, float c1, float c2, float slope) {
+  AGX_CHECK_ARG(A && w && delta && lda >= H && ldd >= H, "agx_delta_init: bad argument");
+  if (R <= 0 || H <= 0) return AGX_OK;
+  hipLaunchKernelGGL(delta_init_kernel, dim3(grid_for((long long)R * H)), dim3(256), 0,
+                     agx::as_stream(stream), A, lda, w, delta, ldd, R, H, n0, n1, c0, c1, c2, slope);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_gp_rownorm_scale(void *stream, float *g, int32_t ldg, float *slopes, int32_t B,
+                                    int32_t G, float coef) {
+  AGX_CHECK_ARG(g && slopes && ldg >= G, "agx_gp_rownorm_scale: bad argument");
+  if (B <= 0) return AGX_OK;
+  hipLaunchKernelGGL(gp_rownorm_scale_kernel, dim3(B), dim3(256), 0, agx::as_stream(stream), g, ldg,
+                     slopes, G, coef);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_wgan_loss(void *stream, const float *out, int32_t n0, int32_t n1,
+                             const float *slopes, int32_t n_slopes, float inv_b, float gp_weight,
+                             float fake_sign, float *losses) {
+  AGX_CHECK_ARG(out && losses && (n_slopes == 0 || slopes), "agx_wgan_loss: null argument");
+  hipLaunchKernelGGL(wgan_loss_kernel, dim3(1), dim3(256), 0, agx::as_stream(stream), out, n0, n1,
+                     slopes, n_slopes, inv_b, gp_weight, fake_sign, losses);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_colsum(void *stream, const float *A, int32_t lda, int32_t r0, int32_t r1,
+                          int32_t H, float *out, int32_t accumulate) {
+  AGX_CHECK_ARG(A && out && lda >= H && r0 >= 0 && r1 >= r0, "agx_colsum: bad argument");
+  if (H <= 0) return AGX_OK;
+  hipLaunchKernelGGL(colsum_kernel, dim3(agx::cdiv(H, 64)), dim3(256), 0, agx::as_stream(stream), A,
+                     lda, r0, r1, H, out, accumulate, 0, 0, 0.f, 0.f, 0.f, 0, (float *)nullptr);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_colsum_weighted(void *stream, const float *A, int32_t lda, int32_t R, int32_t H,
+                                   int32_t n0, int32_t n1, float c0, float c1, float c2, float *out,
+                                   float *bias_out) {
+  AGX_CHECK_ARG(A && out && lda >= H && R >= 0, "agx_colsum_weighted: bad argument");
+  if (H <= 0) return AGX_OK;
+  hipLaunchKernelGGL(colsum_kernel, dim3(agx::cdiv(H, 64)), dim3(256), 0, agx::as_stream(stream), A,
+                     lda, 0, R, H, out, 0, n0, n1, c0, c1, c2, 1, bias_out);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_opt_rmsprop(void *stream, float *w, const float *g, float *rms, int64_t n,
+                               float lr, float rho, float eps, float grad_scale) {
+  AGX_CHECK_ARG(w && g && rms && n >= 0, "agx_opt_rmsprop: bad argument");
+  AGX_CHECK_ARG(agx::aligned16(w) && agx::aligned16(g) && agx::aligned16(rms),
+                "agx_opt_rmsprop: buffers must be 16-byte aligned");
+  if (n == 0) return AGX_OK;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n / 4 + 256, 256, 2048)), dim3(256), 0,
+                     agx::as_stream(stream), w, g, rms, (long long)n, lr, rho, eps, grad_scale);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_opt_adam(void *stream, float *w, const float *g, float *m, float *v, int64_t n,
+                            float lr_t, float beta1, float beta2, float eps, float grad_scale) {
+  AGX_CHECK_ARG(w && g && m && v && n >= 0, "agx_opt_adam: bad argument");
+  if (n == 0) return AGX_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0,
+                     agx::as_stream(stream), w, g, m, v, (long long)n, lr_t, beta1, beta2, eps,
+                     grad_scale);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_rng_normal(void *stream, float *out, int64_t n, uint64_t seed, uint64_t offset) {
+  AGX_CHECK_ARG(out && n >= 0, "agx_rng_normal: bad argument");
+  if (n == 0) return AGX_OK;
+  hipLaunchKernelGGL(rng_kernel<true>, dim3(grid_for((n + 3) / 4)), dim3(256), 0,
+                     agx::as_stream(stream), out, (long long)n, (unsigned long long)seed,
+                     (unsigned long long)offset);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_rng_uniform(void *stream, float *out, int64_t n, uint64_t seed,
+                               uint64_t offset) {
+  AGX_CHECK_ARG(out && n >= 0, "agx_rng_uniform: bad argument");
+  if (n == 0) return AGX_OK;
+  hipLaunchKernelGGL(rng_kernel<false>, dim3(grid_for((n + 3) / 4)), dim3(256), 0,
+                     agx::as_stream(stream), out, (long long)n, (unsigned long long)seed,
+                     (unsigned long long)offset);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}

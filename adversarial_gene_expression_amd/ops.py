@@ -1,0 +1,71 @@
+"""Thin op-level wrappers over the C-ABI (one call = one libagx entry point).
+
+Used by the model ``__call__`` path and by the parity tests; the training step
+itself is sequenced in C++ (csrc/cgan.hip) to keep Python out of the hot loop.
+All arguments and results are device tensors (torch used as allocations only).
+"""
+import torch
+
+from . import _dev, _lib
+from ._dev import ptr
+
+
+def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0, slope=0.0, mask=None,
+         out=None, accumulate=False, force_cfg=-1, force_splitk=0, use_ws=True):
+    """out[M, N] = epilogue(alpha * op(A) @ op(B)); leading dimensions are the row strides."""
+    lib = _lib.load()
+    if out is None:
+        out = _dev.empty((M, _dev.r4(N)))
+    g = _lib.GemmDesc()
+    g.A, g.B, g.C = ptr(A), ptr(B), ptr(out)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = A.stride(0), B.stride(0), out.stride(0)
+    g.ta, g.tb = ta, tb
+    g.alpha = alpha
+    g.bias = ptr(bias)
+    if addrow is not None:
+        g.addrow, g.addmod, g.ldadd = ptr(addrow), addrow.shape[0], addrow.stride(0)
+    g.act, g.slope = act, slope
+    if mask is not None:
+        g.mask, g.ldmask = ptr(mask), mask.stride(0)
+    g.accumulate = int(accumulate)
+    ws = None
+    if use_ws:
+        wsf = max(int(lib.agx_gemm_ws_floats(M, N, K)), (force_splitk if force_splitk > 0 else 0) * M * N)
+        ws = _dev.empty(max(wsf, 1))
+        g.ws, g.ws_floats = ptr(ws), wsf
+    g.force_cfg, g.force_splitk = force_cfg, force_splitk
+    _lib.check(lib.agx_gemm_f32(_dev.stream(), g), 'agx_gemm_f32')
+    return out
+
+
+def colsum(A, r0, r1, H, out=None, accumulate=False):
+    lib = _lib.load()
+    if out is None:
+        out = _dev.zeros(H)
+    _lib.check(lib.agx_colsum(_dev.stream(), ptr(A), A.stride(0), r0, r1, H, ptr(out), int(accumulate)), 'agx_colsum')
+    return out
+
+
+def rmsprop(w, g, rms, lr, rho=0.9, eps=1e-7, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.agx_opt_rmsprop(_dev.stream(), ptr(w), ptr(g), ptr(rms), w.numel(), lr, rho, eps, grad_scale),
+               'agx_opt_rmsprop')
+
+
+def adam(w, g, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.agx_opt_adam(_dev.stream(), ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), lr_t, b1, b2, eps,
+                                grad_scale), 'agx_opt_adam')
+
+
+def rng(n, seed, offset=0, normal=True):
+    lib = _lib.load()
+    out = _dev.empty(n)
+    fn = lib.agx_rng_normal if normal else lib.agx_rng_uniform
+    _lib.check(fn(_dev.stream(), ptr(out), n, seed, offset), 'agx_rng')
+    return out
+
+
+def synchronize():
+    torch.cuda.synchronize()

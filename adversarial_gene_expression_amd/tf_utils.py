@@ -1,0 +1,708 @@
+"""Drop-in mirror of the reference ``tf_utils.py`` (WGAN-GP conditional GAN).
+
+Same public names, argument order, defaults and return conventions as
+``/root/reference/tf_utils.py``; every numeric operation runs in hand-written
+HIP kernels of libagx.so (include/agx.h) on an MI355X.  There is no TensorFlow,
+no autodiff engine and no CPU fallback: the backward pass (including the
+gradient penalty's double-backward) is derived by hand in csrc/cgan.hip.
+
+Differences a caller can see (all additive):
+  * optimizers are ``RMSprop`` / ``Adam`` from this module (Keras-v2 formulas)
+    instead of ``tfk.optimizers.*``;
+  * ``train_disc`` / ``train_gen`` / ``train`` / ``predict`` take optional
+    keyword-only ``alpha=``, ``aug=`` (and ``z=`` where the reference already
+    has it) to inject the random draws TF would make, which is how parity
+    tests feed the oracle and this path identical inputs;
+  * TensorBoard summaries and ``tf.train.Checkpoint`` files are not written
+    (``log_dir`` / ``checkpoint_dir`` are accepted and ignored); ``save_fn`` and
+    ``gen.save`` work (own ``.npz`` format);
+  * under ``torch.distributed`` (one process per GPU) the same functions run
+    batch data-parallel: ``batch_size`` stays the GLOBAL batch, every rank
+    takes its shard and gradients are summed with one RCCL all-reduce per
+    optimizer step.
+"""
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _dev, _lib, ops
+from ._dev import DeviceArray, ptr
+
+tfk = SimpleNamespace()  # populated below with .optimizers.{RMSprop, Adam}
+
+CHECKPOINTS_DIR = '../checkpoints/'
+_LOSS_SLOTS = 64  # floats appended to every flat gradient buffer (loss scalars ride the all-reduce)
+
+
+def limit_gpu(gpu_idx=0, mem=2 * 1024):
+    """Reference ``tf_utils.py:17-38`` pins one GPU and caps TF's allocator.
+    Here it only selects the HIP device (no allocator to cap)."""
+    if torch.cuda.is_available() and gpu_idx < torch.cuda.device_count():
+        torch.cuda.set_device(gpu_idx)
+        print(torch.cuda.device_count(), "Physical GPUs,", 1, "Logical GPUs")
+
+
+# ---------------------------------------------------------------------------
+# random draws (replace tf.random.normal / tf.random.uniform)
+# ---------------------------------------------------------------------------
+
+class _Philox:
+    def __init__(self, seed=0):
+        self.seed, self.offset = int(seed), 0
+
+    def draw(self, shape, normal):
+        lib = _lib.load()
+        n = int(np.prod(shape))
+        out = _dev.empty(shape)
+        fn = lib.agx_rng_normal if normal else lib.agx_rng_uniform
+        _lib.check(fn(_dev.stream(), ptr(out), n, self.seed, self.offset), 'agx_rng')
+        self.offset += (n + 3) & ~3
+        return out
+
+
+_rng = _Philox(0)
+
+
+def set_seed(seed):
+    """Seed the device Philox stream used for z and alpha."""
+    global _rng
+    _rng = _Philox(seed)
+
+
+def random_normal(shape):
+    return _rng.draw(tuple(shape), True)
+
+
+def random_uniform(shape):
+    return _rng.draw(tuple(shape), False)
+
+
+# ---------------------------------------------------------------------------
+# models
+# ---------------------------------------------------------------------------
+
+def _emb_dims(vocab_sizes):
+    return [int(vs ** 0.5) + 1 for vs in vocab_sizes]  # tf_utils.py:65, :121
+
+
+class _Net:
+    """MLP with categorical-covariate embeddings whose parameters live in ONE
+    flat HBM buffer (Keras ``trainable_variables`` order: embedding tables,
+    then kernel/bias per Dense; kernels ``[in, out]`` with a 16-B aligned
+    leading dimension)."""
+
+    kind = None
+
+    def __init__(self, x_dim, vocab_sizes, nb_numeric, h_dims, z_dim, slope=0.0, weights=None, seed=None):
+        if h_dims is None:
+            h_dims = [256, 256]
+        if len(h_dims) < 1 or len(h_dims) + 1 > _lib.AGX_MAX_LAYERS:
+            raise ValueError('h_dims must have between 1 and %d entries' % (_lib.AGX_MAX_LAYERS - 1))
+        if len(vocab_sizes) > _lib.AGX_MAX_CAT:
+            raise ValueError('at most %d categorical covariates' % _lib.AGX_MAX_CAT)
+        self.x_dim, self.z_dim = int(x_dim), int(z_dim)
+        self.vocab_sizes = [int(v) for v in vocab_sizes]
+        self.nb_numeric = int(nb_numeric)
+        self.h_dims = [int(h) for h in h_dims]
+        self.slope = float(slope)
+        self.emb_dims = _emb_dims(self.vocab_sizes)
+        lead = self.z_dim if self.kind == 'gen' else self.x_dim
+        out = self.x_dim if self.kind == 'gen' else 1
+        self.dims = [lead + self.nb_numeric + sum(self.emb_dims)] + self.h_dims + [out]
+        self._layout()
+        self.params = _dev.zeros(self.n_flat)
+        self.grads = _dev.zeros(self.n_flat + _LOSS_SLOTS)
+        self.set_weights(weights if weights is not None else self._initial_weights(seed))
+        self._pair = {}
+        # Keras-like introspection used by the reference (tf_utils.py:201, :371)
+        ins = [SimpleNamespace(shape=(None, lead)), SimpleNamespace(shape=(None, len(self.vocab_sizes))),
+               SimpleNamespace(shape=(None, self.nb_numeric))]
+        self.input = ins
+        self.output = SimpleNamespace(shape=(None, out))
+
+    # -- flat layout ---------------------------------------------------------
+    def _layout(self):
+        off = 0
+        a64 = lambda v: (v + 63) & ~63
+        self.emb_off = []
+        for v, e in zip(self.vocab_sizes, self.emb_dims):
+            self.emb_off.append(off)
+            off = a64(off + v * e)
+        self.ldw, self.w_off, self.b_off = [], [], []
+        for l in range(len(self.dims) - 1):
+            n = self.dims[l + 1]
+            ld = 1 if n == 1 else _dev.r4(n)
+            self.ldw.append(ld)
+            self.w_off.append(off)
+            off = a64(off + self.dims[l] * ld)
+            self.b_off.append(off)
+            off = a64(off + n)
+        self.n_flat = off
+        d = _lib.MlpDesc()
+        d.n_layers = len(self.dims) - 1
+        for i, v in enumerate(self.dims):
+            d.dims[i] = v
+        for l in range(d.n_layers):
+            d.ldw[l], d.w_off[l], d.b_off[l] = self.ldw[l], self.w_off[l], self.b_off[l]
+        d.emb.n_cat = len(self.vocab_sizes)
+        for i in range(d.emb.n_cat):
+            d.emb.vocab[i], d.emb.edim[i], d.emb.table_off[i] = self.vocab_sizes[i], self.emb_dims[i], self.emb_off[i]
+        d.n_num = self.nb_numeric
+        d.n_flat = self.n_flat
+        self.desc = d
+
+    def _initial_weights(self, seed):
+        """Keras defaults: Embedding U(-0.05, 0.05); Dense glorot-uniform, zero bias."""
+        rs = np.random if seed is None else np.random.RandomState(seed)
+        ws = [rs.uniform(-0.05, 0.05, size=(v, e)).astype(np.float32)
+              for v, e in zip(self.vocab_sizes, self.emb_dims)]
+        for l in range(len(self.dims) - 1):
+            lim = math.sqrt(6.0 / (self.dims[l] + self.dims[l + 1]))
+            ws.append(rs.uniform(-lim, lim, size=(self.dims[l], self.dims[l + 1])).astype(np.float32))
+            ws.append(np.zeros(self.dims[l + 1], np.float32))
+        return ws
+
+    def _segments(self):
+        """(flat offset, rows, cols, ld) per variable in Keras order."""
+        segs = [(o, v, e, e) for o, v, e in zip(self.emb_off, self.vocab_sizes, self.emb_dims)]
+        for l in range(len(self.dims) - 1):
+            segs.append((self.w_off[l], self.dims[l], self.dims[l + 1], self.ldw[l]))
+            segs.append((self.b_off[l], 1, self.dims[l + 1], self.dims[l + 1]))
+        return segs
+
+    def _unflatten(self, flat_host):
+        out = []
+        for k, (o, r, c, ld) in enumerate(self._segments()):
+            a = flat_host[o:o + r * ld].reshape(r, ld)[:, :c]
+            is_bias = k >= len(self.vocab_sizes) and (k - len(self.vocab_sizes)) % 2 == 1
+            out.append(a.reshape(-1).copy() if is_bias else a.copy())
+        return out
+
+    def _flatten(self, arrays):
+        segs = self._segments()
+        if len(arrays) != len(segs):
+            raise ValueError('expected %d weight arrays, got %d' % (len(segs), len(arrays)))
+        flat = np.zeros(self.n_flat, np.float32)
+        for a, (o, r, c, ld) in zip(arrays, segs):
+            a = np.asarray(a, np.float32).reshape(r, c)
+            flat[o:o + r * ld].reshape(r, ld)[:, :c] = a
+        return flat
+
+    def get_weights(self):
+        return self._unflatten(self.params.cpu().numpy())
+
+    def set_weights(self, arrays):
+        self.params.copy_(torch.from_numpy(self._flatten(arrays)))
+
+    def get_gradients(self):
+        """Last computed gradients, Keras variable order (host copies)."""
+        return self._unflatten(self.grads[:self.n_flat].cpu().numpy())
+
+    @property
+    def trainable_variables(self):
+        return [DeviceArray(self.params[o:o + r * ld].view(r, ld)[:, :c]) for o, r, c, ld in self._segments()]
+
+    def count_params(self):
+        return sum(r * c for _, r, c, _ in self._segments())
+
+    def summary(self):
+        print('Model: "%s"' % ('generator' if self.kind == 'gen' else 'critic'))
+        names = ['embedding_%d' % i for i in range(len(self.vocab_sizes))]
+        for l in range(len(self.dims) - 1):
+            names += ['dense_%d/kernel' % l, 'dense_%d/bias' % l]
+        for n, (_, r, c, _) in zip(names, self._segments()):
+            print('  %-22s %-16s %d' % (n, (r, c) if r > 1 or 'kernel' in n or 'emb' in n else (c,), r * c))
+        print('Total params: {:,}'.format(self.count_params()))
+
+    def save(self, path):
+        """Own ``.npz`` format (the reference writes Keras H5, gtex_tcga_gan.py:112)."""
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        cfg = dict(kind=self.kind, x_dim=self.x_dim, z_dim=self.z_dim, vocab_sizes=self.vocab_sizes,
+                   nb_numeric=self.nb_numeric, h_dims=self.h_dims, slope=self.slope)
+        np.savez(path, __config__=np.array(repr(cfg)), **{'w%03d' % i: w for i, w in enumerate(self.get_weights())})
+
+    # -- forward (op-level ABI) ---------------------------------------------
+    def _embed_concat(self, lead, cc, nc, rows):
+        lib = _lib.load()
+        width = self.dims[0]
+        ld = _dev.r4(width)
+        out = _dev.zeros((rows, ld))
+        n_lead = lead.shape[1]
+        _lib.check(lib.agx_embed_concat_fwd(_dev.stream(), self.desc.emb, ptr(self.params), ptr(lead), n_lead,
+                                            lead.stride(0), ptr(nc), self.nb_numeric, self.nb_numeric, ptr(cc),
+                                            len(self.vocab_sizes), rows, 0, ptr(out), ld), 'agx_embed_concat_fwd')
+        return out, ld
+
+    def _forward(self, lead, cc, nc, keep=False):
+        rows = lead.shape[0]
+        h, _ = self._embed_concat(lead, cc, nc, rows)
+        acts = [h]
+        nl = len(self.dims) - 1
+        for l in range(nl):
+            n, k = self.dims[l + 1], self.dims[l]
+            w = self.params[self.w_off[l]:self.w_off[l] + k * self.ldw[l]].view(k, self.ldw[l])
+            b = self.params[self.b_off[l]:self.b_off[l] + n]
+            h = ops.gemm(h, w, rows, n, k, bias=b, act=1 if l < nl - 1 else 0, slope=self.slope)
+            acts.append(h)
+        out = h[:, :self.dims[-1]]
+        return (out, acts) if keep else out
+
+    def __call__(self, inputs, training=False):
+        lead, cc, nc = inputs
+        if isinstance(lead, _CriticProbe):
+            return _ProbeResult(self, cc, nc)
+        lead = _dev.to_dev(lead)
+        cc = _dev.to_dev(cc, torch.int32)
+        nc = _dev.to_dev(nc)
+        if lead.dim() != 2 or lead.shape[1] != self.dims[0] - self.nb_numeric - sum(self.emb_dims):
+            raise ValueError('first input must be [batch, %d]' % (self.dims[0] - self.nb_numeric - sum(self.emb_dims)))
+        return DeviceArray(self._forward(lead, cc, nc))
+
+
+class Generator(_Net):
+    kind = 'gen'
+
+
+class Critic(_Net):
+    kind = 'disc'
+
+
+def make_generator(x_dim, vocab_sizes, nb_numeric, h_dims=None, z_dim=10, **kw):
+    """Reference ``tf_utils.py:45-98`` (layer-1 input ``[z | num | emb_0 | emb_1 ...]``)."""
+    model = Generator(x_dim, vocab_sizes, nb_numeric, h_dims, z_dim, **kw)
+    model.summary()  # tf_utils.py:97
+    return model
+
+
+def make_discriminator(x_dim, vocab_sizes, nb_numeric, h_dims=None, **kw):
+    """Reference ``tf_utils.py:101-137`` (layer-1 input ``[x | num | emb_0 | ...]``; linear Dense(1))."""
+    return Critic(x_dim, vocab_sizes, nb_numeric, h_dims, z_dim=1, **kw)
+
+
+def load_model(path):
+    if not os.path.exists(path) and os.path.exists(path + '.npz'):
+        path = path + '.npz'
+    with np.load(path, allow_pickle=False) as f:
+        cfg = eval(str(f['__config__']), {'__builtins__': {}}, {})  # literal dict written by save()
+        ws = [f['w%03d' % i] for i in range(len(f.files) - 1)]
+    cls = Generator if cfg.pop('kind') == 'gen' else Critic
+    return cls(cfg['x_dim'], cfg['vocab_sizes'], cfg['nb_numeric'], cfg['h_dims'], cfg['z_dim'],
+               slope=cfg.get('slope', 0.0), weights=ws)
+
+
+# ---------------------------------------------------------------------------
+# losses (reference surface; tf_utils.py:140-181)
+# ---------------------------------------------------------------------------
+
+def _flat_dev(a):
+    return _dev.to_dev(a).reshape(-1)
+
+
+def wasserstein_loss(y_true, y_pred):
+    """``mean(y_true * y_pred)``  (tf_utils.py:140-144)."""
+    lib = _lib.load()
+    a, b = _flat_dev(y_true), _flat_dev(y_pred)
+    sums = _dev.zeros(8, dtype=torch.float64)
+    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), a.numel(), 0, ptr(sums)), 'agx_pearson_sums')
+    return np.float32(sums[4].item() / a.numel())
+
+
+def _loss_kernel(out, n0, n1, slopes=None, gp_weight=0.0):
+    lib = _lib.load()
+    losses = _dev.empty(4)
+    n = max(n0, n1, 1)
+    _lib.check(lib.agx_wgan_loss(_dev.stream(), ptr(out), n0, n1, ptr(slopes), 0 if slopes is None else slopes.numel(),
+                                 1.0 / n, gp_weight, 1.0, ptr(losses)), 'agx_wgan_loss')
+    return losses
+
+
+def generator_loss(fake_output):
+    """``mean(-fake_output)``  (tf_utils.py:147-151)."""
+    f = _flat_dev(fake_output)
+    return DeviceArray(_loss_kernel(f, f.numel(), 0)[0:1])
+
+
+def discriminator_loss(real_output, fake_output):
+    """``mean(-real) + mean(fake)``  (tf_utils.py:174-181)."""
+    r, f = _flat_dev(real_output), _flat_dev(fake_output)
+    if r.numel() != f.numel():
+        return np.float32(float(generator_loss(r)) - float(generator_loss(f)))
+    return DeviceArray(_loss_kernel(torch.cat([r, f]), r.numel(), f.numel())[0:1])
+
+
+class _CriticProbe:
+    """Stand-in for ``inter`` handed to the user's ``f`` so that the reference call
+    pattern ``gradient_penalty(lambda x: disc([x, cc, nc], training=True), x, x_gen)``
+    (tf_utils.py:218) can be resolved to (critic, cc, nc) without tracing Python."""
+
+
+class _ProbeResult:
+    def __init__(self, net, cc, nc):
+        self.net, self.cc, self.nc = net, cc, nc
+
+
+def _critic_input_gradient(disc, x, cc, nc):
+    """d sum(D(x)) / d x for a ReLU critic, hand-derived chain on the op-level ABI."""
+    lib = _lib.load()
+    rows = x.shape[0]
+    _, acts = disc._forward(x, cc, nc, keep=True)
+    L = len(disc.dims) - 2
+    a = acts[L]
+    d = _dev.empty(a.shape)
+    w_out = disc.params.data_ptr() + 4 * disc.w_off[L]
+    _lib.check(lib.agx_delta_init(_dev.stream(), ptr(a), a.stride(0), w_out, ptr(d), d.stride(0), rows,
+                                  disc.dims[L], 0, 0, 0.0, 0.0, 1.0, disc.slope), 'agx_delta_init')
+    for l in range(L, 0, -1):
+        n = disc.dims[l - 1] if l > 1 else disc.x_dim
+        k = disc.dims[l]
+        w = disc.params[disc.w_off[l - 1]:disc.w_off[l - 1] + disc.dims[l - 1] * disc.ldw[l - 1]].view(
+            disc.dims[l - 1], disc.ldw[l - 1])
+        d = ops.gemm(d, w, rows, n, k, tb=1, slope=disc.slope, mask=acts[l - 1] if l > 1 else None)
+    return d  # [rows, r4(x_dim)]
+
+
+def gradient_penalty(f, real_output, fake_output, alpha=None):
+    """Gradient penalty of WGAN-GP (tf_utils.py:154-171).  ``f`` must be a closure over
+    a critic built by ``make_discriminator`` as in tf_utils.py:218."""
+    lib = _lib.load()
+    res = f(_CriticProbe())
+    if not isinstance(res, _ProbeResult):
+        raise TypeError('gradient_penalty: f must call a critic from make_discriminator on its argument')
+    disc = res.net
+    real, fake = _dev.to_dev(real_output), _dev.to_dev(fake_output)
+    B, G = real.shape
+    a = random_uniform((B,)) if alpha is None else _dev.to_dev(alpha).reshape(-1)
+    inter = _dev.empty((B, G))
+    _lib.check(lib.agx_gp_interp(_dev.stream(), ptr(real), real.stride(0), ptr(fake), fake.stride(0), ptr(a),
+                                 ptr(inter), G, B, G), 'agx_gp_interp')
+    g = _critic_input_gradient(disc, inter, _dev.to_dev(res.cc, torch.int32), _dev.to_dev(res.nc))
+    slopes = _dev.empty(B)
+    _lib.check(lib.agx_gp_rownorm_scale(_dev.stream(), ptr(g), g.stride(0), ptr(slopes), B, G, 0.0),
+               'agx_gp_rownorm_scale')
+    out = _dev.zeros(1)
+    losses = _dev.empty(4)
+    _lib.check(lib.agx_wgan_loss(_dev.stream(), ptr(out), 0, 0, ptr(slopes), B, 1.0 / B, 1.0, 1.0, ptr(losses)),
+               'agx_wgan_loss')
+    return DeviceArray(losses[1:2])
+
+
+# ---------------------------------------------------------------------------
+# optimizers (Keras-v2 semantics; tf_utils.py:285-288)
+# ---------------------------------------------------------------------------
+
+class RMSprop:
+    """``rms = rho*rms + (1-rho) g^2 ; w -= lr * g / (sqrt(rms) + eps)`` (epsilon outside the root)."""
+
+    def __init__(self, learning_rate=0.001, rho=0.9, momentum=0.0, epsilon=1e-7, centered=False, **kw):
+        if momentum != 0.0 or centered:
+            raise NotImplementedError('the reference path uses plain RMSprop (momentum=0, centered=False)')
+        self.learning_rate, self.rho, self.epsilon = float(kw.get('lr', learning_rate)), float(rho), float(epsilon)
+        self._state = {}
+        self.iterations = 0
+
+    def apply(self, net, grad_scale=1.0):
+        lib = _lib.load()
+        rms = self._state.get(id(net))
+        if rms is None:
+            rms = self._state[id(net)] = _dev.zeros(net.n_flat)
+        _lib.check(lib.agx_opt_rmsprop(_dev.stream(), ptr(net.params), ptr(net.grads), ptr(rms), net.n_flat,
+                                       self.learning_rate, self.rho, self.epsilon, grad_scale), 'agx_opt_rmsprop')
+        self.iterations += 1
+
+    def state_arrays(self, net):
+        return {'rms': net._unflatten(self._state[id(net)].cpu().numpy())}
+
+
+class Adam:
+    """Keras-v2 Adam: ``lr_t = lr*sqrt(1-b2^t)/(1-b1^t) ; w -= lr_t * m / (sqrt(v) + eps)``."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, **kw):
+        if amsgrad:
+            raise NotImplementedError('amsgrad')
+        self.learning_rate = float(kw.get('lr', learning_rate))
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        self._state = {}
+        self.iterations = 0
+
+    def apply(self, net, grad_scale=1.0):
+        lib = _lib.load()
+        st = self._state.get(id(net))
+        if st is None:
+            st = self._state[id(net)] = [_dev.zeros(net.n_flat), _dev.zeros(net.n_flat), 0]
+        st[2] += 1
+        t = st[2]
+        lr_t = self.learning_rate * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        _lib.check(lib.agx_opt_adam(_dev.stream(), ptr(net.params), ptr(net.grads), ptr(st[0]), ptr(st[1]), net.n_flat,
+                                    lr_t, self.beta_1, self.beta_2, self.epsilon, grad_scale), 'agx_opt_adam')
+        self.iterations += 1
+
+    def state_arrays(self, net):
+        st = self._state[id(net)]
+        return {'m': net._unflatten(st[0].cpu().numpy()), 'v': net._unflatten(st[1].cpu().numpy())}
+
+
+tfk.optimizers = SimpleNamespace(RMSprop=RMSprop, Adam=Adam)
+
+
+# ---------------------------------------------------------------------------
+# train steps (tf_utils.py:186-258)
+# ---------------------------------------------------------------------------
+
+class _Pair:
+    """C-side step context of one (generator, critic) pair: descriptor + workspace."""
+
+    def __init__(self, gen, disc, max_batch):
+        lib = _lib.load()
+        if gen.x_dim != disc.x_dim or gen.vocab_sizes != disc.vocab_sizes or gen.nb_numeric != disc.nb_numeric:
+            raise ValueError('generator and critic were built for different data / covariates')
+        if gen.slope != disc.slope:
+            raise ValueError('generator and critic must use the same activation slope')
+        cfg = _lib.CganConfig()
+        cfg.x_dim, cfg.z_dim = gen.x_dim, gen.z_dim
+        cfg.gen, cfg.disc = gen.desc, disc.desc
+        cfg.slope = gen.slope
+        cfg.max_batch = max_batch
+        self.max_batch = max_batch
+        self.handle = _lib.C.c_void_p()
+        _lib.check(lib.agx_cgan_create(cfg, _lib.C.byref(self.handle)), 'agx_cgan_create')
+        nbytes = int(lib.agx_cgan_workspace_bytes(self.handle))
+        self.workspace = _dev.zeros(nbytes // 4 + 64)
+        _lib.check(lib.agx_cgan_bind(self.handle, ptr(gen.params), ptr(gen.grads), ptr(disc.params), ptr(disc.grads),
+                                     ptr(self.workspace), self.workspace.numel() * 4), 'agx_cgan_bind')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().agx_cgan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _pair(gen, disc, batch):
+    p = gen._pair.get(id(disc))
+    if p is None or p.max_batch < batch:
+        _dev.device()
+        p = gen._pair[id(disc)] = _Pair(gen, disc, max(batch, 32))
+    return p
+
+
+def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def _allreduce_grads(net):
+    import torch.distributed as dist
+    dist.all_reduce(net.grads)  # RCCL sum over xGMI; loss slots ride along
+
+
+_TRACE_CONSTS = {}
+
+
+def _aug_constants(tag, key, p_aug, norm_scale, bs, nb_genes):
+    """The reference draws augmentation masks/noise with NumPy INSIDE ``@tf.function``
+    (tf_utils.py:202, :209-210, :240, :247), so they are constants of each trace
+    (one per input shape).  Same here: drawn once per (function, models, batch shape)
+    with the same NumPy calls in the same order, then reused."""
+    k = (tag,) + key
+    c = _TRACE_CONSTS.get(k)
+    if c is None:
+        augs = np.random.binomial(1, p_aug, bs)
+        if tag == 'disc':
+            nf = np.random.normal(0, norm_scale, nb_genes)
+            nr = np.random.normal(0, norm_scale, (bs, nb_genes))
+            c = {'mask': augs, 'noise_fake': nf, 'noise_real': nr}
+        else:
+            c = {'mask': augs, 'noise': np.random.normal(0, norm_scale, (bs, nb_genes))}
+        c = {n: _dev.to_dev(v) for n, v in c.items()}
+        _TRACE_CONSTS[k] = c
+    return c
+
+
+def _step_args(pair, z, cc, nc, B, B_global, losses):
+    a = _lib.StepArgs()
+    a.z, a.cat, a.num = ptr(z), ptr(cc), ptr(nc)
+    a.B, a.B_global = B, B_global
+    a.losses = losses
+    return a
+
+
+def train_disc(x, z, cc, nc, gen, disc, disc_opt, grad_penalty_weight=10, p_aug=0, norm_scale=0.5, *,
+               alpha=None, aug=None, batch_global=None, apply=True):
+    """Train critic (reference ``tf_utils.py:186-223``).  Returns the critic loss.
+
+    alpha: optional [B] / [B,1] GP interpolation coefficients (TF draws U[0,1), :162).
+    aug:   optional dict(mask=[B], noise_fake=[G], noise_real=[B,G]) overriding the
+           per-trace NumPy constants of :202, :209-210.
+    """
+    lib = _lib.load()
+    z = _dev.to_dev(z)
+    B = z.shape[0]
+    x = _dev.to_dev(x)
+    cc = _dev.to_dev(cc, torch.int32)
+    nc = _dev.to_dev(nc)
+    if x.shape != (B, gen.x_dim):
+        raise ValueError('x must be [%d, %d], got %s' % (B, gen.x_dim, tuple(x.shape)))
+    pair = _pair(gen, disc, B)
+    world, _ = _world()
+    Bg = int(batch_global) if batch_global else B * world
+    alpha = random_uniform((B,)) if alpha is None else _dev.to_dev(alpha).reshape(-1)
+    losses = disc.grads.data_ptr() + 4 * disc.n_flat
+    a = _step_args(pair, z, cc, nc, B, Bg, losses)
+    a.x, a.ldx = ptr(x), x.stride(0)
+    a.alpha = ptr(alpha)
+    a.gp_weight = float(grad_penalty_weight)
+    keep = None
+    if aug is None and p_aug:
+        aug = _aug_constants('disc', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
+    if aug is not None:
+        keep = (_dev.to_dev(aug['mask']).reshape(-1), _dev.to_dev(aug['noise_fake']).reshape(-1),
+                _dev.to_dev(aug['noise_real']))
+        a.aug_mask, a.aug_noise_fake, a.aug_noise_real = ptr(keep[0]), ptr(keep[1]), ptr(keep[2])
+    _lib.check(lib.agx_cgan_disc_grads(pair.handle, _dev.stream(), a), 'agx_cgan_disc_grads')
+    if world > 1:
+        _allreduce_grads(disc)
+    if apply:
+        disc_opt.apply(disc)
+    return DeviceArray(disc.grads[disc.n_flat + 2:disc.n_flat + 3].clone())
+
+
+def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None, batch_global=None, apply=True):
+    """Train generator (reference ``tf_utils.py:226-258``).  Returns the generator loss.
+
+    aug: optional dict(mask=[B], noise=[B,G]) overriding the per-trace constants of :240, :247."""
+    lib = _lib.load()
+    z = _dev.to_dev(z)
+    B = z.shape[0]
+    cc = _dev.to_dev(cc, torch.int32)
+    nc = _dev.to_dev(nc)
+    pair = _pair(gen, disc, B)
+    world, _ = _world()
+    Bg = int(batch_global) if batch_global else B * world
+    losses = gen.grads.data_ptr() + 4 * gen.n_flat
+    a = _step_args(pair, z, cc, nc, B, Bg, losses)
+    keep = None
+    if aug is None and p_aug:
+        aug = _aug_constants('gen', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
+    if aug is not None:
+        keep = (_dev.to_dev(aug['mask']).reshape(-1), _dev.to_dev(aug['noise']))
+        a.aug_mask, a.aug_noise_fake = ptr(keep[0]), ptr(keep[1])
+    _lib.check(lib.agx_cgan_gen_grads(pair.handle, _dev.stream(), a), 'agx_cgan_gen_grads')
+    if world > 1:
+        _allreduce_grads(gen)
+    if apply:
+        gen_opt.apply(gen)
+    return DeviceArray(gen.grads[gen.n_flat:gen.n_flat + 1].clone())
+
+
+def _shard(lo, hi, world, rank):
+    """Rows [lo, hi) of the global batch owned by `rank` (sizes differ by at most 1)."""
+    n = hi - lo
+    base, rem = divmod(n, world)
+    start = lo + rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def train(dataset, cat_covs, num_covs, z_dim, epochs, batch_size, gen, disc, score_fn, save_fn,
+          gen_opt=None, disc_opt=None, nb_critic=5, verbose=True, checkpoint_dir='./checkpoints/cpkt',
+          log_dir='./logs/', patience=10, p_aug=0, norm_scale=0.5, *, noise_fn=None):
+    """Train model (reference ``tf_utils.py:261-356``): sequential un-shuffled mini-batches
+    including the ragged tail, ``nb_critic`` critic steps (fresh z, same real batch) then one
+    generator step, evaluation / ``save_fn`` / patience every 5 epochs.
+
+    The training matrix is uploaded to HBM once and batches are device slices.
+    noise_fn(kind, shape): optional injection of the TF draws (kind in {'z', 'alpha'}) for the
+    GLOBAL batch; default is the device Philox stream.  Returns a trace dict (additive)."""
+    if gen_opt is None:
+        gen_opt = RMSprop(5e-4)   # tf_utils.py:285-288
+    if disc_opt is None:
+        disc_opt = RMSprop(5e-4)
+    world, rank = _world()
+    data = _dev.to_dev(dataset)
+    ccs = _dev.to_dev(cat_covs, torch.int32)
+    ncs = _dev.to_dev(num_covs)
+    n = data.shape[0]
+
+    def draw(kind, rows, cols, lo, hi):
+        if noise_fn is not None:
+            full = _dev.to_dev(noise_fn(kind, (rows, cols)))
+        else:
+            full = random_normal((rows, cols)) if kind == 'z' else random_uniform((rows, cols))
+        return full[lo:hi].contiguous()
+
+    best_score = -np.inf
+    initial_patience = patience
+    trace = {'gen_loss': [], 'disc_loss': [], 'score': [], 'saved': [], 'patience': []}
+    for epoch in range(epochs):
+        gl, dl = [], []
+        for i in range(0, n, batch_size):
+            hi = min(n, i + batch_size)
+            bg = hi - i
+            lo_r, hi_r = _shard(i, hi, world, rank)
+            if hi_r <= lo_r:
+                raise ValueError('global batch of %d rows cannot be split over %d ranks' % (bg, world))
+            x, cc, nc = data[lo_r:hi_r], ccs[lo_r:hi_r], ncs[lo_r:hi_r]
+            disc_loss = None
+            for _ in range(nb_critic):   # tf_utils.py:316-318
+                z = draw('z', bg, z_dim, lo_r - i, hi_r - i)
+                al = draw('alpha', bg, 1, lo_r - i, hi_r - i)
+                disc_loss = train_disc(x, z, cc, nc, gen, disc, disc_opt, p_aug=p_aug, norm_scale=norm_scale,
+                                       alpha=al, batch_global=bg)
+            dl.append(disc_loss)         # only the last critic loss is averaged (:319)
+            z = draw('z', bg, z_dim, lo_r - i, hi_r - i)
+            gl.append(train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=p_aug, norm_scale=norm_scale, batch_global=bg))
+
+        gen_mean = _mean32(gl)
+        disc_mean = _mean32(dl)
+        if epoch % 5 == 0:               # tf_utils.py:333-343 (checkpoint.save dropped)
+            score = score_fn(gen)
+            if score > best_score:
+                if rank == 0:
+                    print('Saving model ...')
+                    save_fn()
+                best_score = score
+                patience = initial_patience
+                trace['saved'].append(epoch)
+            else:
+                patience -= 1
+            trace['score'].append(float(score))
+            if verbose and rank == 0:
+                print('Score: {:.3f}'.format(score))
+        if verbose and rank == 0:
+            print('Epoch {}. Gen loss: {:.2f}. Disc loss: {:.2f}'.format(epoch + 1, gen_mean, disc_mean))
+        trace['gen_loss'].append(float(gen_mean))
+        trace['disc_loss'].append(float(disc_mean))
+        trace['patience'].append(patience)
+        if patience == 0:
+            break
+    return trace
+
+
+def _mean32(device_scalars):
+    """Keras ``metrics.Mean(dtype=float32)``: fp32 running total / count; one D2H per epoch."""
+    if not device_scalars:
+        return np.float32(0)
+    vals = torch.cat([d.tensor.reshape(1) for d in device_scalars]).cpu().numpy()
+    total = np.float32(0)
+    for v in vals:
+        total = np.float32(total + v)
+    return np.float32(total / np.float32(len(vals)))
+
+
+def predict(cc, nc, gen, z=None, training=False):
+    """Make predictions (reference ``tf_utils.py:359-376``): NumPy out unless ``training``."""
+    nb_samples = cc.shape[0]
+    if z is None:
+        z_dim = gen.input[0].shape[-1]
+        z = random_normal([nb_samples, z_dim])
+    out = gen([z, cc, nc], training=training)
+    if not training:
+        return out.numpy()
+    return out

@@ -1,0 +1,215 @@
+"""Drop-in mirror of the correlation / data helpers of the reference ``utils.py``.
+
+Same names, argument meaning and error behaviour as the reference
+(``/root/reference/utils.py:260-282, 808-873``); the arithmetic runs in HIP
+kernels of libagx.so on an MI355X.  NumPy in -> NumPy out, like the reference.
+Device tensors (torch, cuda) in -> ``DeviceArray`` out (no host round trip).
+
+Precision note: the kernels compute in fp32 (exact-fp32 MFMA).  float64 inputs
+(the reference then computes in float64) are accepted, computed in fp32 and
+returned as float64, i.e. they agree with the reference to fp32 accuracy only.
+"""
+import numpy as np
+import torch
+
+from . import _dev, _lib
+from ._dev import DeviceArray, ptr
+
+
+def _is_dev(a):
+    return isinstance(a, DeviceArray) or (isinstance(a, torch.Tensor) and a.is_cuda)
+
+
+def _out(t, like_dev, dtype):
+    if like_dev:
+        return DeviceArray(t)
+    a = t.cpu().numpy()
+    return a.astype(dtype) if a.dtype != dtype else a
+
+
+def _in_dtype(*arrs):
+    for a in arrs:
+        if isinstance(a, np.ndarray) and a.dtype == np.float64:
+            return np.float64
+    return np.float32
+
+
+# ---------------------------------------------------------------------------
+# device-level building blocks
+# ---------------------------------------------------------------------------
+
+def _colstats_dev(xd, ld, n, g):
+    lib = _lib.load()
+    mean = _dev.empty(g)
+    std = _dev.empty(g)
+    ws = _dev.empty(2 * g, dtype=torch.float64)
+    _lib.check(lib.agx_colstats(_dev.stream(), ptr(xd), ld, n, g, ptr(mean), ptr(std), ptr(ws)), 'agx_colstats')
+    return mean, std
+
+
+def _standardize_dev(xd, ld, n, g, mean, std):
+    lib = _lib.load()
+    out = _dev.empty((n, ld))
+    if ld != g:
+        out[:, g:].zero_()
+    _lib.check(lib.agx_standardize(_dev.stream(), ptr(xd), ld, n, g, ptr(mean), ptr(std), ptr(out), ld),
+               'agx_standardize')
+    return out
+
+
+def _std_columns_dev(x):
+    xd, ld = _dev.padded_matrix(x)
+    n, g = xd.shape[0], (x.shape[1])
+    mean, std = _colstats_dev(xd, ld, n, g)
+    return _standardize_dev(xd, ld, n, g, mean, std), ld, n, g
+
+
+def _corr_self_dev(x, tile_range=None):
+    """G x G Pearson matrix of the columns of x (device tensor [G, ldc])."""
+    lib = _lib.load()
+    xs, ld, n, g = _std_columns_dev(x)
+    ldc = _dev.r4(g)
+    c = _dev.empty((g, ldc))
+    tb, te = tile_range if tile_range is not None else (0, -1)
+    _lib.check(lib.agx_corr_xtx(_dev.stream(), ptr(xs), ld, n, g, 1.0 / n, ptr(c), ldc, tb, te), 'agx_corr_xtx')
+    return c, ldc, g
+
+
+def _corr_bipartite_dev(x, y):
+    lib = _lib.load()
+    xs, ldx, n, g1 = _std_columns_dev(x)
+    ys, ldy, _, g2 = _std_columns_dev(y)
+    ldc = _dev.r4(g2)
+    c = _dev.empty((g1, ldc))
+    ws_floats = int(lib.agx_gemm_ws_floats(g1, g2, n))
+    ws = _dev.empty(max(ws_floats, 1))
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = ptr(xs), ptr(ys), ptr(c)
+    d.M, d.N, d.K = g1, g2, n
+    d.lda, d.ldb, d.ldc = ldx, ldy, ldc
+    d.ta, d.tb = 1, 0
+    d.alpha = 1.0 / n
+    d.ws, d.ws_floats = ptr(ws), ws_floats
+    d.force_cfg, d.force_splitk = -1, 0
+    _lib.check(lib.agx_gemm_f32(_dev.stream(), d), 'agx_gemm_f32')
+    return c, ldc, g1, g2
+
+
+def _pearson_1d_dev(a, b, one_minus=False):
+    """Scalar Pearson r of two equally long device vectors (five fp64 sums on
+    device, closed form on host).  Follows utils.py:816-824 for 1-D inputs."""
+    lib = _lib.load()
+    n = a.numel()
+    sums = _dev.zeros(8, dtype=torch.float64)
+    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums)), 'agx_pearson_sums')
+    return _r_from_sums(sums.cpu().numpy(), n)
+
+
+def _r_from_sums(s, n):
+    with np.errstate(all='ignore'):
+        ma, mb = s[0] / n, s[1] / n
+        va, vb = s[2] / n - ma * ma, s[3] / n - mb * mb
+        cov = s[4] / n - ma * mb
+        return np.float32(cov / (np.sqrt(max(va, 0.0)) * np.sqrt(max(vb, 0.0))))
+
+
+def _triu_pack_dev(c, ldc, g):
+    lib = _lib.load()
+    out = _dev.empty(max(g * (g - 1) // 2, 1))
+    counts = _dev.empty(g + 1, dtype=torch.int64)
+    offs = _dev.empty(g + 1, dtype=torch.int64)
+    total = _dev.zeros(1, dtype=torch.int64)
+    _lib.check(lib.agx_triu_pack(_dev.stream(), ptr(c), ldc, g, ptr(out), ptr(counts), ptr(offs), ptr(total)),
+               'agx_triu_pack')
+    return out[:int(total.item())]
+
+
+# ---------------------------------------------------------------------------
+# reference surface
+# ---------------------------------------------------------------------------
+
+def standardize(x, mean=None, std=None):
+    """Shape x: (nb_samples, nb_vars).  Reference ``utils.py:260-268``."""
+    lib = _lib.load()
+    dev_in = _is_dev(x)
+    dt = _in_dtype(x)
+    xd, ld = _dev.padded_matrix(x)
+    n, g = xd.shape[0], (x.shape[1])
+    if mean is None or std is None:
+        m_, s_ = _colstats_dev(xd, ld, n, g)
+    mean_d = m_ if mean is None else _dev.to_dev(np.broadcast_to(np.asarray(mean, np.float32), (g,)))
+    std_d = s_ if std is None else _dev.to_dev(np.broadcast_to(np.asarray(std, np.float32), (g,)))
+    out = _standardize_dev(xd, ld, n, g, mean_d, std_d)
+    return _out(out[:, :g], dev_in, dt)
+
+
+def split_train_test(x, train_rate=0.75):
+    """Head/tail split (pure indexing, stays on the host).  Reference ``utils.py:271-282``."""
+    nb_samples = x.shape[0]
+    split_point = int(train_rate * nb_samples)
+    return x[:split_point], x[split_point:]
+
+
+def pearson_correlation(x, y):
+    """Pearson matrix between the columns of x and of y (or scalar r for 1-D
+    inputs).  Reference ``utils.py:808-824``; same AssertionError on a
+    sample-count mismatch, same silent NaN/inf for zero-variance columns."""
+    assert x.shape[0] == y.shape[0]
+    dev_in = _is_dev(x)
+    dt = _in_dtype(x, y)
+    if len(x.shape) == 1:
+        r = _pearson_1d_dev(_dev.to_dev(x).reshape(-1), _dev.to_dev(y).reshape(-1))
+        return r if dt == np.float32 else np.float64(r)
+    if x is y:
+        c, ldc, g = _corr_self_dev(x)
+        return _out(c[:, :g], dev_in, dt)
+    c, ldc, g1, g2 = _corr_bipartite_dev(x, y)
+    return _out(c[:, :g2], dev_in, dt)
+
+
+def upper_diag_list(m_):
+    """Condensed strict upper triangle, row-major, NaNs dropped.  Reference ``utils.py:837-849``."""
+    dev_in = _is_dev(m_)
+    dt = _in_dtype(m_)
+    md, ld = _dev.padded_matrix(m_)
+    g = md.shape[0]
+    if m_.shape[0] != m_.shape[1]:
+        raise ValueError('upper_diag_list expects a square matrix')
+    return _out(_triu_pack_dev(md, ld, g), dev_in, dt)
+
+
+def correlations_list(x, y, corr_fn=pearson_correlation):
+    """Reference ``utils.py:852-860``."""
+    if corr_fn is pearson_correlation and x is y:
+        dev_in = _is_dev(x)
+        c, ldc, g = _corr_self_dev(x)
+        return _out(_triu_pack_dev(c, ldc, g), dev_in, _in_dtype(x))
+    return upper_diag_list(corr_fn(x, y))
+
+
+def gamma_coef(x, y):
+    """Gamma(D^X, D^Z) = Pearson r between the condensed distance lists
+    ``1 - corr``.  Reference ``utils.py:863-873``.
+
+    Both G x G matrices stay in HBM.  Without NaNs the five sums are taken
+    straight over the two upper triangles (the 2 x G(G-1)/2 lists are never
+    built); if any NaN is present the lists are packed with the reference's
+    NaN-dropping and the reference's length assertion applies."""
+    lib = _lib.load()
+    dt = _in_dtype(x, y)
+    cx, ldx, g = _corr_self_dev(x)
+    cy, ldy, g2 = _corr_self_dev(y)
+    if g != g2:
+        # lists of different length: reference fails at utils.py:821
+        raise AssertionError
+    sums = _dev.zeros(8, dtype=torch.float64)
+    _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, ptr(sums)), 'agx_gamma_sums')
+    s = sums.cpu().numpy()
+    if s[5] == 0:
+        r = _r_from_sums(s, g * (g - 1) // 2)
+    else:
+        lx = _triu_pack_dev(cx, ldx, g)
+        ly = _triu_pack_dev(cy, ldy, g)
+        assert lx.shape[0] == ly.shape[0]
+        r = _pearson_1d_dev(lx, ly, one_minus=True)
+    return r if dt == np.float32 else np.float64(r)

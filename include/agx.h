@@ -1,0 +1,227 @@
+/*
+ * agx.h - C-ABI of libagx.so: MI355X (gfx950) kernels for the WGAN-GP cGAN
+ * train step and the gene x gene Pearson / gamma evaluation of
+ * rvinas/adversarial-gene-expression.
+ *
+ * The reference has NO native/FFI layer: its boundary is the Python function
+ * surface of tf_utils.py / utils.py.  Each entry point
+ * below therefore cites the reference Python lines whose arithmetic it
+ * replaces; the Python mirror (adversarial_gene_expression_amd/{tf_utils,utils}.py)
+ * binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - matrices are fp32 row-major with an explicit leading dimension (floats);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns 0 on success, <0 = AGX_E_*; agx_last_error()
+ *     gives a thread-local message.  Nothing throws across the ABI;
+ *   - no entry point allocates or frees device memory; scratch comes in via
+ *     explicit workspace arguments whose size is given by a *_ws_bytes query.
+ */
+#ifndef AGX_H
+#define AGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGX_OK 0
+#define AGX_E_INVALID -1  /* bad argument / shape / alignment */
+#define AGX_E_HIP -2      /* a HIP runtime call failed */
+#define AGX_E_WORKSPACE -3 /* workspace too small */
+#define AGX_E_STATE -4    /* handle not bound / wrong call order */
+
+#define AGX_MAX_LAYERS 8
+#define AGX_MAX_CAT 16
+
+/* ---- library ---------------------------------------------------------- */
+int agx_version(void);
+const char *agx_last_error(void);
+/* Select `device`, verify it is a gfx950 part, cache its CU count. */
+int agx_init(int device);
+
+/* ---- dense layers: tf_utils.py:85-88, 132-135 (Dense+ReLU) and their
+ *      autodiff (MatMul grads / BiasAddGrad / ReluGrad, tf_utils.py:220,255) -- */
+typedef struct agx_gemm {
+  /* C[M,N] = epilogue( alpha * op_a(A) . op_b(B) ) on fp32 MFMA (exact fp32). */
+  const float *A; /* ta=0: [M,K] lda ; ta=1: stored [K,M] lda  (dW = X^T . delta) */
+  const float *B; /* tb=0: [K,N] ldb ; tb=1: stored [N,K] ldb  (dX = delta . W^T) */
+  float *C;       /* [M,N] ldc */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t ta, tb;
+  float alpha;
+  const float *bias;    /* [N] or NULL: + bias[n]                               */
+  const float *addrow;  /* [addmod, N] ld=ldadd or NULL: + addrow[m % addmod][n] */
+  int32_t addmod, ldadd;
+  int32_t act;          /* 0 none; 1 leaky-ReLU with `slope` (0 => ReLU)         */
+  float slope;
+  const float *mask;    /* [M,N] ld=ldmask or NULL: v *= (mask>0 ? 1 : slope);   */
+  int32_t ldmask;       /*   may alias C (in-place ReLU-grad)                    */
+  int32_t accumulate;   /* 1: C += result                                        */
+  float *ws;            /* split-K scratch (floats) or NULL                      */
+  int64_t ws_floats;
+  int32_t force_cfg;    /* -1 auto; 0 = 128x128, 1 = 64x64, 2 = 32x128 tiles     */
+  int32_t force_splitk; /* <=0 auto                                              */
+} agx_gemm_t;
+int agx_gemm_f32(void *stream, const agx_gemm_t *p);
+/* Upper bound on the split-K scratch (floats) the heuristic may ask for. */
+int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K);
+
+/* ---- embeddings: tf_utils.py:64-76, 120-131 ---------------------------- */
+typedef struct agx_embed {
+  int32_t n_cat;
+  int32_t vocab[AGX_MAX_CAT];
+  int32_t edim[AGX_MAX_CAT];
+  int64_t table_off[AGX_MAX_CAT]; /* float offset of table i inside `tables` */
+} agx_embed_t;
+/* out[b,:] = [ lead[s, 0:n_lead] | num[s, 0:n_num] | emb_0[cat[s,0]] | emb_1[cat[s,1]] ... ]
+ * with source row s = b % row_mod (row_mod <= 0: s = b), so that one launch can fill the
+ * covariate columns of the stacked [real; fake; interpolated] critic batch.  Indices outside
+ * [0, vocab) give a zero row (TF GPU Embedding semantics).                                   */
+int agx_embed_concat_fwd(void *stream, const agx_embed_t *e, const float *tables,
+                         const float *lead, int32_t n_lead, int32_t ld_lead,
+                         const float *num, int32_t n_num, int32_t ld_num,
+                         const int32_t *cat, int32_t ld_cat, int32_t B, int32_t row_mod,
+                         float *out, int32_t ldo);
+/* grad_tables[i][v,:] (+)= sum_{b: cat[b % row_mod, i]==v} dout[b, col0 + off_i : +edim_i]
+ * (duplicates summed in a fixed order; deterministic).  accumulate=0 overwrites. */
+int agx_embed_bwd(void *stream, const agx_embed_t *e, float *grad_tables,
+                  const float *dout, int32_t ldd, int32_t col0,
+                  const int32_t *cat, int32_t ld_cat, int32_t B, int32_t row_mod,
+                  int32_t accumulate);
+
+/* ---- elementwise / reductions of the WGAN-GP loss: tf_utils.py:140-181 -- */
+/* inter = real + alpha[b] * (fake - real)            (tf_utils.py:162-164) */
+int agx_gp_interp(void *stream, const float *real, int32_t ldr, const float *fake, int32_t ldf,
+                  const float *alpha, float *inter, int32_t ldi, int32_t B, int32_t G);
+/* x[b,:] += mask[b] * noise[(row_bcast ? 0 : b), :]  (tf_utils.py:209-210, 247) */
+int agx_aug_add(void *stream, float *x, int32_t ldx, const float *mask, const float *noise,
+                int32_t ldn, int32_t row_bcast, int32_t B, int32_t G);
+/* out[r] = A[r,:] . w + b[0]  (the critic's Dense(1), tf_utils.py:135) */
+int agx_rowdot(void *stream, const float *A, int32_t lda, const float *w, const float *b,
+               float *out, int32_t R, int32_t H);
+/* delta[r,j] = act'(A[r,j]) * c(r) * w[j];  c = c0 for r<n0, c1 for n0<=r<n0+n1, c2 after
+ * (seed of the hand-derived backward; c = -1/B real, +1/B fake, 1 for the GP rows) */
+int agx_delta_init(void *stream, const float *A, int32_t lda, const float *w, float *delta,
+                   int32_t ldd, int32_t R, int32_t H, int32_t n0, int32_t n1,
+                   float c0, float c1, float c2, float slope);
+/* GP slopes: s[b] = sqrt(sum_g g[b,g]^2) (NO epsilon, tf_utils.py:169);
+ * then g[b,:] *= coef * (s-1)/s  (d gp / d g with coef = weight*2/B_global).   */
+int agx_gp_rownorm_scale(void *stream, float *g, int32_t ldg, float *slopes, int32_t B,
+                         int32_t G, float coef);
+/* losses[0] = -sum(out[0:n0])*inv_b + sum(out[n0:n0+n1])*inv_b   (tf_utils.py:174-181)
+ * losses[1] = sum((slopes-1)^2)*inv_b                            (tf_utils.py:170)
+ * losses[2] = losses[0] + gp_weight*losses[1]                    (tf_utils.py:217-218)
+ * n0 = 0 gives the generator loss mean(-D(fake)) with sign=-1    (tf_utils.py:147-151) */
+int agx_wgan_loss(void *stream, const float *out, int32_t n0, int32_t n1, const float *slopes,
+                  int32_t n_slopes, float inv_b, float gp_weight, float fake_sign, float *losses);
+/* out[j] = sum_{r0<=r<r1} A[r,j]  (BiasAddGrad; deterministic) ; accumulate=1 adds */
+int agx_colsum(void *stream, const float *A, int32_t lda, int32_t r0, int32_t r1, int32_t H,
+               float *out, int32_t accumulate);
+/* out[j] = sum_r c(r) * A[r,j], c as in agx_delta_init; out[H] (if bias_out) = sum_r<n0+n1 c(r) */
+int agx_colsum_weighted(void *stream, const float *A, int32_t lda, int32_t R, int32_t H,
+                        int32_t n0, int32_t n1, float c0, float c1, float c2, float *out,
+                        float *bias_out);
+
+/* ---- optimizers: tf_utils.py:221, 256, 285-288 (Keras-v2 semantics) ---- */
+/* rms = rho*rms + (1-rho) g^2 ; w -= lr * g / (sqrt(rms) + eps) */
+int agx_opt_rmsprop(void *stream, float *w, const float *g, float *rms, int64_t n, float lr,
+                    float rho, float eps, float grad_scale);
+/* m,v EMA ; w -= lr_t * m / (sqrt(v) + eps), lr_t computed by the caller */
+int agx_opt_adam(void *stream, float *w, const float *g, float *m, float *v, int64_t n,
+                 float lr_t, float beta1, float beta2, float eps, float grad_scale);
+
+/* ---- RNG (replaces tf.random.normal/uniform, tf_utils.py:162,317,322,372) */
+/* Philox4x32-10; the stream is a deterministic function of (seed, offset, i); callers
+ * advance `offset` by the (4-rounded) number of values drawn. */
+int agx_rng_normal(void *stream, float *out, int64_t n, uint64_t seed, uint64_t offset);
+int agx_rng_uniform(void *stream, float *out, int64_t n, uint64_t seed, uint64_t offset);
+
+/* ---- correlation path: utils.py:260-268, 808-873 ------------------------ */
+/* per-column mean and population std (ddof=0) of x[N,G]; sums in fp64.
+ * ws: 2*G doubles of scratch.  (utils.py:816-818, 264-267) */
+int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G, float *mean,
+                 float *std, double *ws);
+/* out = (x - mean) / std  (utils.py:268, 819) */
+int agx_standardize(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
+                    const float *mean, const float *std, float *out, int32_t ldo);
+/* C[G,G] = alpha * Xs^T Xs exploiting symmetry (utils.py:824 with x is y); tile rows
+ * [tile_begin, tile_end) of the upper-triangular 128x128 tile list are computed, so
+ * that the list can be dealt across GPUs; pass 0, -1 for all tiles.    */
+int agx_corr_xtx(void *stream, const float *xs, int32_t ldx, int32_t N, int32_t G, float alpha,
+                 float *C, int32_t ldc, int64_t tile_begin, int64_t tile_end);
+int64_t agx_corr_num_tiles(int32_t G);
+/* Condensed strict upper triangle, row-major order, NaNs dropped (utils.py:837-849).
+ * row_counts/row_offsets: G+1 int64 scratch each; *n_out_dev receives the length.   */
+int agx_triu_pack(void *stream, const float *C, int32_t ldc, int32_t G, float *out,
+                  int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev);
+/* sums[0..4] (fp64) += sum a, sum b, sum a^2, sum b^2, sum ab over two fp32 vectors
+ * transformed as (one_minus ? 1-v : v); the 1-D Pearson of utils.py:872 follows on host. */
+int agx_pearson_sums(void *stream, const float *a, const float *b, int64_t n, int32_t one_minus,
+                     double *sums);
+/* Same five sums taken directly over the strict upper triangles of two G x G matrices
+ * (1 - c), plus sums[5] = number of NaN entries met (then the caller must use the
+ * packed path to reproduce the reference's NaN-dropping).  utils.py:863-873 fused. */
+int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const float *C2, int32_t ld2,
+                   int32_t G, double *sums);
+
+/* ---- whole train step: tf_utils.py:186-258 ------------------------------ */
+typedef struct agx_mlp_desc {
+  int32_t n_layers;                 /* Dense layers incl. the output layer      */
+  int32_t dims[AGX_MAX_LAYERS + 1]; /* dims[0] = layer-1 input width            */
+  int32_t ldw[AGX_MAX_LAYERS];      /* leading dim of kernel l ([in,out] layout) */
+  int64_t w_off[AGX_MAX_LAYERS];    /* float offsets into the flat buffer       */
+  int64_t b_off[AGX_MAX_LAYERS];
+  agx_embed_t emb;                  /* table_off are flat offsets too           */
+  int32_t n_num;
+  int64_t n_flat;                   /* flat length incl. padding                */
+} agx_mlp_desc_t;
+
+typedef struct agx_cgan_config {
+  int32_t x_dim, z_dim;
+  agx_mlp_desc_t gen, disc;
+  float slope;                      /* 0 = ReLU (reference)                     */
+  int32_t max_batch;
+} agx_cgan_config_t;
+
+typedef struct agx_cgan agx_cgan_t; /* opaque; host memory only */
+int agx_cgan_create(const agx_cgan_config_t *cfg, agx_cgan_t **out);
+int agx_cgan_destroy(agx_cgan_t *h);
+int64_t agx_cgan_workspace_bytes(const agx_cgan_t *h);
+int agx_cgan_bind(agx_cgan_t *h, float *gen_params, float *gen_grads, float *disc_params,
+                  float *disc_grads, void *workspace, int64_t workspace_bytes);
+
+/* Generator forward (tf_utils.py:359-376 predict; :206): out[B, x_dim]. */
+int agx_cgan_gen_forward(agx_cgan_t *h, void *stream, const float *z, const int32_t *cat,
+                         const float *num, int32_t B, float *out, int32_t ldo);
+/* Critic forward on given x: scores[B] (diagnostics / tests). */
+int agx_cgan_disc_forward(agx_cgan_t *h, void *stream, const float *x, int32_t ldx,
+                          const int32_t *cat, const float *num, int32_t B, float *scores);
+
+typedef struct agx_step_args {
+  const float *x;      /* real batch [B, x_dim] (critic step only)              */
+  int32_t ldx;
+  const float *z;      /* [B, z_dim]                                             */
+  const int32_t *cat;  /* [B, n_cat]                                             */
+  const float *num;    /* [B, n_num]                                             */
+  const float *alpha;  /* [B] GP interpolation coefficients (critic step only)   */
+  int32_t B;           /* local batch                                            */
+  int32_t B_global;    /* divisor of the means (== B on one GPU)                 */
+  float gp_weight;     /* 10 (tf_utils.py:187)                                   */
+  const float *aug_mask;       /* [B] or NULL   (tf_utils.py:202, 240)           */
+  const float *aug_noise_fake; /* critic: [x_dim] broadcast row (:209); gen: [B,x_dim] (:247) */
+  const float *aug_noise_real; /* critic: [B, x_dim] (:210)                      */
+  float *losses;       /* device [4]: wgan term, gp, total, unused               */
+} agx_step_args_t;
+/* Gradients of one critic step into disc_grads (tf_utils.py:204-220); no optimizer. */
+int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a);
+/* Gradients of one generator step into gen_grads (tf_utils.py:242-255). */
+int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGX_H */

@@ -1,0 +1,232 @@
+"""WGAN-GP train step on the GPU (C-ABI agx_cgan_*) against the torch-CPU fp64 autograd oracle.
+
+The reference pins nothing here (TF absent, no tests): "parity unpinned"; the oracle restates
+tf_utils.py:45-258 line by line.  fp32 tolerances: losses 1e-5 relative; every gradient
+max|err| <= 3e-5 * max|grad| + 1e-7; weights after n RMSprop steps: see test_weights_after_steps."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import keras_list, make_problem, t64, tl
+from oracle import cgan_oracle as O
+from oracle import corr_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(p, slope=0.0):
+    from adversarial_gene_expression_amd import tf_utils as T
+    gen = T.Generator(p['G'], p['V'], p['n_num'], p['H'], p['Z'], weights=keras_list(p['gp']), slope=slope)
+    disc = T.Critic(p['G'], p['V'], p['n_num'], p['H'], 1, weights=keras_list(p['dp']), slope=slope)
+    return T, gen, disc
+
+
+def _f32(p, k):
+    return np.asarray(p[k], np.float32)
+
+
+def _check_grads(got, want, rtol=3e-5):
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        b = np.asarray(b).reshape(a.shape)
+        err = np.max(np.abs(a - b)) if a.size else 0.0
+        assert err <= rtol * np.max(np.abs(b)) + 1e-7, ('variable %d' % i, err, np.max(np.abs(b)))
+
+
+CFGS = [dict(), dict(B=1, seed=2), dict(B=12, H=(16,), seed=3), dict(B=33, H=(24, 16), G=130, seed=4),
+        dict(B=7, H=(12, 10, 8), V=(6, 8, 5, 11, 5, 3, 5), Z=10, seed=5),
+        dict(B=4, n_num=2, num_zero=False, seed=7), dict(B=32, G=300, H=(128, 128), V=(15, 3), Z=64, seed=8)]
+
+
+@pytest.mark.parametrize('cfg', CFGS)
+def test_forward_matches_oracle(gpu, cfg):
+    p = make_problem(**cfg)
+    T, gen, disc = _models(p)
+    xg = gen([_f32(p, 'z'), p['cc'], _f32(p, 'nc')]).numpy()
+    want = O.gen_forward(O.to_torch(p['gp']), t64(p['z']), tl(p['cc']), t64(p['nc'])).numpy()
+    np.testing.assert_allclose(xg, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))
+    sc = disc([_f32(p, 'x'), p['cc'], _f32(p, 'nc')]).numpy()
+    want = O.disc_forward(O.to_torch(p['dp']), t64(p['x']), tl(p['cc']), t64(p['nc'])).numpy()
+    np.testing.assert_allclose(sc, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))
+    assert T.predict(p['cc'], _f32(p, 'nc'), gen, z=_f32(p, 'z')).shape == (p['B'], p['G'])
+
+
+@pytest.mark.parametrize('cfg', CFGS)
+def test_disc_step_loss_and_grads(gpu, cfg):
+    p = make_problem(**cfg)
+    T, gen, disc = _models(p)
+    loss = T.train_disc(_f32(p, 'x'), _f32(p, 'z'), p['cc'], _f32(p, 'nc'), gen, disc, T.RMSprop(5e-4),
+                        alpha=_f32(p, 'alpha'), apply=False)
+    want_loss, want_gp, want = O.disc_loss_and_grads(t64(p['x']), t64(p['z']), tl(p['cc']), t64(p['nc']),
+                                                     O.to_torch(p['gp']), O.to_torch(p['dp']), t64(p['alpha']))
+    assert abs(float(loss) - float(want_loss)) <= 1e-5 * max(1.0, abs(float(want_loss)))
+    _check_grads(disc.get_gradients(), [g.numpy() for g in want])
+
+
+def test_disc_step_with_augmentation_and_leaky_slope(gpu):
+    p = make_problem(B=6, seed=11)
+    rs = np.random.RandomState(1)
+    aug = dict(mask=rs.binomial(1, 0.5, 6).astype(np.float32), noise_fake=rs.normal(0, 0.5, p['G']).astype(np.float32),
+               noise_real=rs.normal(0, 0.5, (6, p['G'])).astype(np.float32))
+    T, gen, disc = _models(p)
+    loss = T.train_disc(_f32(p, 'x'), _f32(p, 'z'), p['cc'], _f32(p, 'nc'), gen, disc, T.RMSprop(5e-4),
+                        alpha=_f32(p, 'alpha'), aug=aug, apply=False)
+    wl, _, want = O.disc_loss_and_grads(t64(p['x']), t64(p['z']), tl(p['cc']), t64(p['nc']), O.to_torch(p['gp']),
+                                        O.to_torch(p['dp']), t64(p['alpha']), aug_mask=t64(aug['mask']),
+                                        aug_noise_fake=t64(aug['noise_fake']), aug_noise_real=t64(aug['noise_real']))
+    assert abs(float(loss) - float(wl)) <= 1e-5 * max(1.0, abs(float(wl)))
+    _check_grads(disc.get_gradients(), [g.numpy() for g in want])
+    # generator step with its [B, G] noise
+    gl = T.train_gen(_f32(p, 'z'), p['cc'], _f32(p, 'nc'), gen, disc, T.RMSprop(5e-4),
+                     aug=dict(mask=aug['mask'], noise=aug['noise_real']), apply=False)
+    wl, want = O.gen_loss_and_grads(t64(p['z']), tl(p['cc']), t64(p['nc']), O.to_torch(p['gp']), O.to_torch(p['dp']),
+                                    aug_mask=t64(aug['mask']), aug_noise=t64(aug['noise_real']))
+    assert abs(float(gl) - float(wl)) <= 1e-5 * max(1.0, abs(float(wl)))
+    _check_grads(gen.get_gradients(), [g.numpy() for g in want])
+
+
+def test_leaky_slope_matches_closed_form(gpu):
+    """slope > 0 (north_star's LeakyReLU option) against the NumPy restatement of the same backward."""
+    from oracle import cgan_closed_form as CF
+    p = make_problem(B=9, seed=21)
+    T, gen, disc = _models(p, slope=0.2)
+    loss = T.train_disc(_f32(p, 'x'), _f32(p, 'z'), p['cc'], _f32(p, 'nc'), gen, disc, T.RMSprop(5e-4),
+                        alpha=_f32(p, 'alpha'), apply=False)
+    losses, want = CF.disc_grads(p['x'], p['z'], p['cc'], p['nc'], p['gp'], p['dp'], p['alpha'], slope=0.2)
+    assert abs(float(loss) - losses[2]) <= 1e-5 * max(1.0, abs(losses[2]))
+    _check_grads(disc.get_gradients(), CF.flat(want))
+
+
+@pytest.mark.parametrize('cfg', CFGS)
+def test_gen_step_loss_and_grads(gpu, cfg):
+    p = make_problem(**cfg)
+    T, gen, disc = _models(p)
+    loss = T.train_gen(_f32(p, 'z'), p['cc'], _f32(p, 'nc'), gen, disc, T.RMSprop(5e-4), apply=False)
+    want_loss, want = O.gen_loss_and_grads(t64(p['z']), tl(p['cc']), t64(p['nc']), O.to_torch(p['gp']),
+                                           O.to_torch(p['dp']))
+    assert abs(float(loss) - float(want_loss)) <= 1e-5 * max(1.0, abs(float(want_loss)))
+    _check_grads(gen.get_gradients(), [g.numpy() for g in want])
+    # the critic is untouched by a generator step
+    for a, b in zip(disc.get_weights(), keras_list(p['dp'])):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('opt', ['rmsprop', 'adam'])
+def test_weights_after_steps(gpu, opt):
+    """5 x (5 critic + 1 generator) steps with injected z / alpha.
+
+    RMSprop/Adam divide by sqrt(EMA(g^2)) + 1e-7, so an entry whose gradient is ~1e-7 turns an fp32
+    rounding difference into an O(lr) difference of its update ('RMSprop
+    sensitivity').  Stated tolerance: 99.9 % of all weights within 2e-6, every weight within
+    n_steps * lr * sqrt(10) (the largest possible RMSprop displacement)."""
+    p = make_problem(B=12, G=61, H=(24, 16), seed=31)
+    T, gen, disc = _models(p)
+    lr = 5e-4
+    mk = (lambda: T.RMSprop(lr)) if opt == 'rmsprop' else (lambda: T.Adam(lr))
+    mko = (lambda: O.RMSprop(lr)) if opt == 'rmsprop' else (lambda: O.Adam(lr))
+    go, do = mk(), mk()
+    tg, td = O.to_torch(p['gp']), O.to_torch(p['dp'])
+    ogo, odo = mko(), mko()
+    rs = np.random.RandomState(5)
+    losses, olosses = [], []
+    n_it = 5
+    for it in range(n_it):
+        for _ in range(5):
+            z, al = rs.randn(12, p['Z']), rs.rand(12, 1)
+            losses.append(float(T.train_disc(_f32(p, 'x'), z.astype(np.float32), p['cc'], _f32(p, 'nc'), gen, disc, do,
+                                             alpha=al.astype(np.float32))))
+            olosses.append(float(O.train_disc(t64(p['x']), t64(z), tl(p['cc']), t64(p['nc']), tg, td, odo, t64(al))[0]))
+        z = rs.randn(12, p['Z'])
+        losses.append(float(T.train_gen(z.astype(np.float32), p['cc'], _f32(p, 'nc'), gen, disc, go)))
+        olosses.append(float(O.train_gen(t64(z), tl(p['cc']), t64(p['nc']), tg, td, ogo)[0]))
+    np.testing.assert_allclose(losses, olosses, rtol=2e-4, atol=2e-4)
+    for net, tp, steps in ((gen, tg, n_it), (disc, td, 5 * n_it)):
+        got = np.concatenate([w.reshape(-1) for w in net.get_weights()])
+        want = np.concatenate([t.detach().numpy().reshape(-1) for t in O.param_list(tp)])
+        err = np.abs(got - want)
+        assert np.quantile(err, 0.999) < 2e-6, np.quantile(err, 0.999)
+        assert err.max() <= steps * lr * np.sqrt(10) + 1e-6, err.max()
+
+
+def _noise_factory():
+    rs = np.random.RandomState(77)
+    return lambda kind, shape: rs.randn(*shape) if kind == 'z' else rs.rand(*shape)
+
+
+def test_train_loop_trace_matches_oracle(gpu):
+    from adversarial_gene_expression_amd import tf_utils as T, utils as U
+    p = make_problem(G=37, B=70, seed=41)
+    _, gen, disc = _models(p)
+    x32 = p['x'].astype(np.float32)
+    zt = np.random.RandomState(9).randn(70, p['Z'])
+    saved = []
+    n1 = _noise_factory()
+    tr = T.train(x32, p['cc'], _f32(p, 'nc'), p['Z'], 6, 32, gen, disc,
+                 lambda g: U.gamma_coef(x32, T.predict(p['cc'], _f32(p, 'nc'), g, z=zt.astype(np.float32))),
+                 lambda: saved.append(1), verbose=False, noise_fn=lambda k, s: n1(k, s).astype(np.float32))
+    tg, td = O.to_torch(p['gp']), O.to_torch(p['dp'])
+    osaved = []
+    n2 = _noise_factory()
+    otr = O.train(p['x'], p['cc'], p['nc'], p['Z'], 6, 32, tg, td,
+                  lambda gp_: CO.gamma_coef(p['x'], O.predict(tl(p['cc']), t64(p['nc']), gp_, t64(zt))),
+                  lambda: osaved.append(1), O.RMSprop(5e-4), O.RMSprop(5e-4), n2)
+    np.testing.assert_allclose(tr['gen_loss'], otr['gen_loss'], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(tr['disc_loss'], otr['disc_loss'], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(tr['score'], otr['score'], atol=2e-3)
+    assert len(tr['score']) == 2 and len(saved) == len(osaved)      # evaluated at epochs 0 and 5
+    assert tr['patience'] == otr['patience'] and tr['saved'] == otr['saved']
+
+
+def test_reference_surface(gpu):
+    """Names, defaults and call patterns a user of the reference relies on."""
+    import inspect
+    from adversarial_gene_expression_amd import tf_utils as T
+    for name in ['limit_gpu', 'make_generator', 'make_discriminator', 'wasserstein_loss', 'generator_loss',
+                 'gradient_penalty', 'discriminator_loss', 'train_disc', 'train_gen', 'train', 'predict']:
+        assert callable(getattr(T, name))
+    sig = inspect.signature(T.train)
+    assert [k for k in sig.parameters][:10] == ['dataset', 'cat_covs', 'num_covs', 'z_dim', 'epochs', 'batch_size',
+                                                'gen', 'disc', 'score_fn', 'save_fn']
+    assert sig.parameters['nb_critic'].default == 5 and sig.parameters['patience'].default == 10
+    assert sig.parameters['norm_scale'].default == 0.5 and sig.parameters['p_aug'].default == 0
+    assert inspect.signature(T.train_disc).parameters['grad_penalty_weight'].default == 10
+    assert inspect.signature(T.train_gen).parameters['norm_scale'].default == 1
+    p = make_problem(B=5, seed=3)
+    _, gen, disc = _models(p)
+    assert gen.output.shape[-1] == p['G'] and gen.input[0].shape[-1] == p['Z']
+    assert gen.count_params() == sum(a.size for a in keras_list(p['gp']))
+    # loss helpers (tf_utils.py:140-181)
+    rs = np.random.RandomState(0)
+    r, f = rs.randn(9, 1).astype(np.float32), rs.randn(9, 1).astype(np.float32)
+    np.testing.assert_allclose(float(T.generator_loss(f)), -f.mean(), atol=1e-6)
+    np.testing.assert_allclose(float(T.discriminator_loss(r, f)), -r.mean() + f.mean(), atol=1e-6)
+    np.testing.assert_allclose(float(T.wasserstein_loss(-np.ones_like(r), r)), -r.mean(), atol=1e-6)
+    # gradient_penalty with the reference's closure (tf_utils.py:218)
+    cc, nc = p['cc'], _f32(p, 'nc')
+    xr, xf = _f32(p, 'x'), rs.randn(5, p['G']).astype(np.float32)
+    gp = T.gradient_penalty(lambda x: disc([x, cc, nc], training=True), xr, xf, alpha=_f32(p, 'alpha'))
+    dp_ = O.to_torch(p['dp'])
+    want = O.gradient_penalty(lambda xi: O.disc_forward(dp_, xi, tl(cc), t64(nc)), t64(xr), t64(xf), t64(p['alpha']))
+    np.testing.assert_allclose(float(gp), float(want), rtol=2e-5)
+    # save / load round trip
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'models', 'gen_test.h5')
+        gen.save(path)
+        g2 = T.load_model(path)
+        for a, b in zip(gen.get_weights(), g2.get_weights()):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_ragged_and_max_batch_growth(gpu):
+    """Step context grows when a larger batch arrives; a ragged tail (12) after 32 reuses it."""
+    p32 = make_problem(B=40, seed=51)
+    T, gen, disc = _models(p32)
+    for B in (32, 12, 40):
+        s = slice(0, B)
+        loss = T.train_disc(_f32(p32, 'x')[s], _f32(p32, 'z')[s], p32['cc'][s], _f32(p32, 'nc')[s], gen, disc,
+                            T.RMSprop(5e-4), alpha=_f32(p32, 'alpha')[s], apply=False)
+        wl, _, want = O.disc_loss_and_grads(t64(p32['x'][s]), t64(p32['z'][s]), tl(p32['cc'][s]), t64(p32['nc'][s]),
+                                            O.to_torch(p32['gp']), O.to_torch(p32['dp']), t64(p32['alpha'][s]))
+        assert abs(float(loss) - float(wl)) <= 1e-5 * max(1.0, abs(float(wl)))
+        _check_grads(disc.get_gradients(), [g.numpy() for g in want])

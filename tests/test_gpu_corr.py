@@ -1,0 +1,124 @@
+"""Correlation / gamma path on the GPU against the reference's golden vectors and the NumPy oracle.
+
+Tolerances (fp32): Pearson matrix |err| <= 3e-6 for N <= 300 (fp32 fma chain over N products of
+O(1) terms, then /N), gamma <= 2e-5."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+from helpers import lowrank
+from oracle import corr_oracle as CO
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'corr_n*.npz')))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_against_reference_goldens(gpu, name):
+    from adversarial_gene_expression_amd import utils as U
+    g = golden(name)
+    x, y, y2 = g['x'], g['y'], g['y2']
+    tol = 3e-6
+    pxx = U.pearson_correlation(x, x)
+    assert pxx.dtype == x.dtype and pxx.shape == g['pearson_xx'].shape
+    np.testing.assert_allclose(pxx, g['pearson_xx'], rtol=0, atol=tol, equal_nan=True)
+    np.testing.assert_allclose(U.pearson_correlation(x, y), g['pearson_xy'], rtol=0, atol=tol, equal_nan=True)
+    np.testing.assert_array_equal(U.upper_diag_list(g['pearson_xx']), g['upper_xx'])   # pure data movement: bit exact
+    cl = U.correlations_list(x, x)
+    assert cl.shape == g['corr_list_xx'].shape
+    np.testing.assert_allclose(cl, g['corr_list_xx'], rtol=0, atol=tol)
+    np.testing.assert_allclose(U.standardize(x), g['standardize_x'], rtol=2e-5, atol=2e-6, equal_nan=True)
+    np.testing.assert_allclose(U.standardize(x, mean=np.mean(y, axis=0), std=np.std(y, axis=0)),
+                               g['standardize_x_with_y_stats'], rtol=1e-6, atol=1e-6)
+    tr, te = U.split_train_test(x)
+    np.testing.assert_array_equal(tr, g['split_train'])
+    np.testing.assert_array_equal(te, g['split_test'])
+    np.testing.assert_allclose(U.pearson_correlation(g['a1d'], g['b1d']), g['pearson_1d'], atol=2e-6)
+    np.testing.assert_allclose(U.gamma_coef(x, x), g['gamma_x_x'], atol=2e-5)
+    if 'gamma_x_y2' in g.files:
+        got = U.gamma_coef(x, y2)
+        assert got.dtype == g['gamma_x_y2'].dtype
+        np.testing.assert_allclose(got, g['gamma_x_y2'], atol=2e-5)
+
+
+def test_upper_diag_list_drops_genuine_nans(gpu):
+    from adversarial_gene_expression_amd import utils as U
+    g = golden('corr_upper_nan.npz')
+    np.testing.assert_array_equal(U.upper_diag_list(g['m']), g['upper'])
+
+
+def test_errors_match_reference(gpu):
+    from adversarial_gene_expression_amd import utils as U
+    with pytest.raises(AssertionError):
+        U.pearson_correlation(np.zeros((4, 3), np.float32), np.zeros((5, 3), np.float32))
+
+
+@pytest.mark.parametrize('N,G', [(227, 1076), (680, 1076), (300, 2111)])
+def test_against_oracle_ecoli_shapes(gpu, N, G):
+    from adversarial_gene_expression_amd import utils as U
+    rs = np.random.RandomState(G)
+    x = lowrank(rs, N, G, k=16)
+    y = lowrank(rs, N // 2 + 5, G, k=16)
+    np.testing.assert_allclose(U.pearson_correlation(x, x), CO.pearson_correlation(x, x), rtol=0, atol=5e-6)
+    np.testing.assert_array_equal(U.upper_diag_list(CO.pearson_correlation(x, x)),
+                                  CO.upper_diag_list(CO.pearson_correlation(x, x)))
+    np.testing.assert_allclose(U.gamma_coef(x, y), CO.gamma_coef_f64(x, y), atol=2e-5)
+
+
+def test_unshifted_data_is_centred_before_the_product(gpu):
+    """log1p-like data (mean 5, sd 1): statistics in fp64 keep the fp32 result well conditioned."""
+    from adversarial_gene_expression_amd import utils as U
+    rs = np.random.RandomState(0)
+    x = (lowrank(rs, 500, 300, k=8) * 0.3 + 5.0).astype(np.float32)
+    ref = np.corrcoef(x.astype(np.float64).T)
+    np.testing.assert_allclose(U.pearson_correlation(x, x), ref, rtol=0, atol=1e-5)
+
+
+def test_full_size_properties(gpu):
+    """GTEx eval shape (N=2287, G=18154): symmetry (bitwise), unit diagonal, |r|<=1, spot values
+    against fp64 on a random subset of gene pairs, and gamma(x, x) == 1."""
+    import torch
+    from adversarial_gene_expression_amd import utils as U
+    N, G = 2287, 18154
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    f = torch.randn(N, 32, device='cuda', generator=gen)
+    l = torch.randn(32, G, device='cuda', generator=gen)
+    x = f @ l + 0.5 * torch.randn(N, G, device='cuda', generator=gen)
+    c = U.pearson_correlation(x, x).tensor
+    assert c.shape == (G, G)
+    assert torch.equal(c, c.t())
+    assert float((torch.diagonal(c) - 1).abs().max()) < 1e-5
+    assert float(c.abs().max()) <= 1 + 1e-5
+    idx = torch.randint(0, G, (64,), device='cuda', generator=gen)
+    xs = x[:, idx].double()
+    xs = (xs - xs.mean(0)) / xs.std(0, unbiased=False)
+    ref = xs.t() @ xs / N
+    assert float((c[idx][:, idx].double() - ref).abs().max()) < 1e-5
+    assert abs(float(U.gamma_coef(x, x)) - 1.0) < 1e-5
+    packed = U.upper_diag_list(U.pearson_correlation(x, x)).tensor
+    assert packed.numel() == G * (G - 1) // 2
+    iu = torch.triu_indices(G, G, 1, device='cuda')
+    probe = torch.randint(0, packed.numel(), (4096,), device='cuda', generator=gen)
+    assert torch.equal(packed[probe], c[iu[0][probe], iu[1][probe]])
+
+
+def test_tile_ranges_compose(gpu):
+    """2D tiling across GPUs: disjoint tile ranges of the upper-triangular tile list fill the same matrix."""
+    import torch
+    from adversarial_gene_expression_amd import _dev, _lib, utils as U
+    from adversarial_gene_expression_amd._dev import ptr
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    x = lowrank(rs, 100, 700, k=8)
+    full, ldc, g = U._corr_self_dev(x)
+    nt = int(lib.agx_corr_num_tiles(700))
+    assert nt == 6 * 7 // 2
+    xs, ld, n, g = U._std_columns_dev(x)
+    c = torch.full((g, ldc), float('nan'), device=gpu)
+    for r in range(4):   # 4 "ranks", cyclic blocks of the tile list
+        lo, hi = r * nt // 4, (r + 1) * nt // 4
+        _lib.check(lib.agx_corr_xtx(_dev.stream(), ptr(xs), ld, n, g, 1.0 / n, ptr(c), ldc, lo, hi))
+    assert torch.equal(c[:, :g], full[:, :g])

@@ -1,0 +1,139 @@
+"""fp32-MFMA GEMM family (csrc/gemm.hip) against NumPy fp64 through the C-ABI.
+Tolerance: fp32 fma-chain accumulation => |err| <= 2e-6 * sum|a*b| (stated bound, K <= 4096)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_mat(a, pad_ld=True):
+    from adversarial_gene_expression_amd import _dev
+    t, _ = _dev.padded_matrix(a) if pad_ld else (_dev.to_dev(a), None)
+    return t
+
+
+def _ref(A, B, ta, tb):
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    return (A64.T if ta else A64) @ (B64.T if tb else B64)
+
+
+def _bound(A, B, ta, tb):
+    return (np.abs(A.T if ta else A).astype(np.float64) @ np.abs(B.T if tb else B).astype(np.float64))
+
+
+SHAPES = [(1, 1, 1), (5, 37, 16), (32, 256, 71), (33, 130, 65), (96, 64, 300), (12, 257, 129),
+          (128, 128, 32), (129, 127, 33), (200, 70, 1030)]
+
+
+@pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 0)])
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 2])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_gemm_layouts_configs(gpu, layout, cfg, shape):
+    from adversarial_gene_expression_amd import ops
+    ta, tb = layout
+    M, N, K = shape
+    rs = np.random.RandomState(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rs.randn(*((K, M) if ta else (M, K))).astype(np.float32)
+    B = rs.randn(*((N, K) if tb else (K, N))).astype(np.float32)
+    out = ops.gemm(_dev_mat(A), _dev_mat(B), M, N, K, ta=ta, tb=tb, force_cfg=cfg)
+    got = out.cpu().numpy()[:, :N]
+    err = np.abs(got - _ref(A, B, ta, tb))
+    assert np.all(err <= 2e-6 * _bound(A, B, ta, tb) + 1e-30)
+
+
+@pytest.mark.parametrize('splitk', [2, 5, 64])
+@pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 0)])
+def test_gemm_splitk(gpu, layout, splitk):
+    from adversarial_gene_expression_amd import ops
+    ta, tb = layout
+    M, N, K = 45, 70, 1111
+    rs = np.random.RandomState(splitk)
+    A = rs.randn(*((K, M) if ta else (M, K))).astype(np.float32)
+    B = rs.randn(*((N, K) if tb else (K, N))).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    from adversarial_gene_expression_amd import _dev
+    out = ops.gemm(_dev_mat(A), _dev_mat(B), M, N, K, ta=ta, tb=tb, force_splitk=splitk, bias=_dev.to_dev(bias), act=1)
+    ref = np.maximum(_ref(A, B, ta, tb) + bias, 0)
+    err = np.abs(out.cpu().numpy()[:, :N] - ref)
+    assert np.all(err <= 2e-6 * (_bound(A, B, ta, tb) + np.abs(bias)) + 1e-30)
+
+
+def test_gemm_unaligned_operands_take_scalar_path(gpu):
+    """ld not a multiple of 4 and a base pointer off 16 B: the non-vector loader must be used."""
+    from adversarial_gene_expression_amd import ops, _dev
+    rs = np.random.RandomState(1)
+    M, N, K = 37, 18, 53
+    A = rs.randn(M, K).astype(np.float32)
+    B = rs.randn(K, N).astype(np.float32)
+    Ad = _dev.to_dev(A)                         # ld = 53
+    Bbuf = _dev.zeros(K * N + 1)
+    Bd = Bbuf[1:].view(K, N)                    # base + 4 B
+    Bd.copy_(torch.from_numpy(B))
+    out = ops.gemm(Ad, Bd, M, N, K)
+    np.testing.assert_allclose(out.cpu().numpy()[:, :N], A.astype(np.float64) @ B, rtol=0, atol=2e-5)
+
+
+def test_gemm_epilogues(gpu):
+    from adversarial_gene_expression_amd import ops, _dev
+    rs = np.random.RandomState(5)
+    M, N, K = 36, 50, 40
+    A, B = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    add = rs.randn(12, N).astype(np.float32)
+    mask = rs.randn(M, N).astype(np.float32)
+    base = A.astype(np.float64) @ B
+    Ad, Bd = _dev_mat(A), _dev_mat(B)
+    # bias + leaky relu
+    got = ops.gemm(Ad, Bd, M, N, K, bias=_dev.to_dev(bias), act=1, slope=0.2).cpu().numpy()[:, :N]
+    v = base + bias
+    np.testing.assert_allclose(got, np.where(v > 0, v, 0.2 * v), atol=3e-5)
+    # alpha + addrow (row modulo)
+    got = ops.gemm(Ad, Bd, M, N, K, alpha=0.5, addrow=_dev_mat(add)).cpu().numpy()[:, :N]
+    np.testing.assert_allclose(got, 0.5 * base + add[np.arange(M) % 12], atol=3e-5)
+    # separate mask (ReLU grad) and in-place mask
+    got = ops.gemm(Ad, Bd, M, N, K, mask=_dev_mat(mask)).cpu().numpy()[:, :N]
+    np.testing.assert_allclose(got, np.where(mask > 0, base, 0.0), atol=3e-5)
+    C = _dev_mat(mask).clone()
+    ops.gemm(Ad, Bd, M, N, K, mask=C, out=C, slope=0.1)
+    np.testing.assert_allclose(C.cpu().numpy()[:, :N], np.where(mask > 0, base, 0.1 * base), atol=3e-5)
+    # accumulate
+    C = _dev_mat(mask).clone()
+    ops.gemm(Ad, Bd, M, N, K, out=C, accumulate=True)
+    np.testing.assert_allclose(C.cpu().numpy()[:, :N], mask + base, atol=3e-5)
+
+
+def test_gemm_identity_with_asymmetric_b(gpu):
+    """A = I with an asymmetric B catches a swapped row/col map in the C write."""
+    from adversarial_gene_expression_amd import ops
+    n = 96
+    B = (np.arange(n)[:, None] * 1000 + np.arange(n)[None, :]).astype(np.float32)
+    for cfg in (0, 1, 2):
+        out = ops.gemm(_dev_mat(np.eye(n, dtype=np.float32)), _dev_mat(B), n, n, n, force_cfg=cfg)
+        np.testing.assert_array_equal(out.cpu().numpy()[:, :n], B)
+
+
+def test_gemm_rejects_bad_arguments(gpu):
+    from adversarial_gene_expression_amd import ops, _dev, AgxError
+    a = _dev.zeros((8, 8))
+    with pytest.raises(AgxError):
+        ops.gemm(a, a, 8, 8, 8, ta=1, tb=1)
+    with pytest.raises(AgxError):
+        ops.gemm(a, a, 8, 16, 8)  # ldb < N
+
+
+def test_gemm_gtex_shapes_bitwise_reproducible(gpu):
+    """Full-size layer shapes (B=32 and 512): linearity in A and run-to-run bitwise equality."""
+    from adversarial_gene_expression_amd import ops, _dev
+    G, H = 18154, 256
+    torch.manual_seed(0)
+    W = torch.randn(G + 7, H, device=gpu)
+    for B in (32, 512):
+        X = torch.randn(3 * B, _dev.r4(G + 7), device=gpu)
+        y1 = ops.gemm(X, W, 3 * B, H, G + 7)
+        y2 = ops.gemm(X, W, 3 * B, H, G + 7)
+        assert torch.equal(y1, y2)
+        y3 = ops.gemm(2.0 * X, W, 3 * B, H, G + 7)
+        assert torch.equal(y3, 2.0 * y1)   # scaling by 2 is exact in fp32
+        ref = (X[:, :G + 7].double() @ W.double())
+        assert float((y1[:, :H].double() - ref).abs().max()) < 5e-3  # K=18161, |sum| ~ 135

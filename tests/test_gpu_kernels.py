@@ -1,0 +1,196 @@
+"""HBM-bound kernels of the train step (csrc/elementwise.hip) against NumPy, through the C-ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _libs():
+    from adversarial_gene_expression_amd import _dev, _lib
+    return _dev, _lib, _lib.load()
+
+
+def _embed_desc(_lib, vocab, edim, offs):
+    e = _lib.EmbedDesc()
+    e.n_cat = len(vocab)
+    for i, (v, d, o) in enumerate(zip(vocab, edim, offs)):
+        e.vocab[i], e.edim[i], e.table_off[i] = v, d, o
+    return e
+
+
+@pytest.mark.parametrize('B,row_mod', [(1, 0), (12, 0), (33, 0), (36, 12)])
+def test_embed_concat_fwd_bwd(gpu, B, row_mod):
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    rs = np.random.RandomState(B)
+    vocab, edim = [6, 8, 5, 11], [3, 3, 3, 4]
+    offs, off = [], 0
+    for v, d in zip(vocab, edim):
+        offs.append(off)
+        off += (v * d + 63) & ~63
+    tables = rs.randn(off).astype(np.float32)
+    src = row_mod or B
+    lead = rs.randn(src, 5).astype(np.float32)
+    num = rs.randn(src, 2).astype(np.float32)
+    cat = np.stack([rs.randint(0, v, src) for v in vocab], 1).astype(np.int32)
+    width = 5 + 2 + sum(edim)
+    e = _embed_desc(_lib, vocab, edim, offs)
+    out = _dev.zeros((B, width + 3))
+    td, ld_, nd, cd = _dev.to_dev(tables), _dev.to_dev(lead), _dev.to_dev(num), _dev.to_dev(cat, torch.int32)
+    _lib.check(lib.agx_embed_concat_fwd(_dev.stream(), e, ptr(td), ptr(ld_), 5, 5, ptr(nd), 2, 2, ptr(cd), 4, B,
+                                        row_mod, ptr(out), width + 3))
+    rows = np.arange(B) % src
+    ref = np.concatenate([lead[rows], num[rows]] + [tables[o:o + v * d].reshape(v, d)[cat[rows, i]]
+                                                     for i, (v, d, o) in enumerate(zip(vocab, edim, offs))], 1)
+    np.testing.assert_array_equal(out.cpu().numpy()[:, :width], ref)
+    # backward: scatter-add (duplicates summed), untouched rows get exact zeros
+    dout = rs.randn(B, width + 3).astype(np.float32)
+    grad = _dev.to_dev(np.full(off, 7.0, np.float32))
+    _lib.check(lib.agx_embed_bwd(_dev.stream(), e, ptr(grad), ptr(_dev.to_dev(dout)), width + 3, 7, ptr(cd), 4, B,
+                                 row_mod, 0))
+    g = grad.cpu().numpy()
+    c0 = 7
+    for i, (v, d, o) in enumerate(zip(vocab, edim, offs)):
+        want = np.zeros((v, d))
+        np.add.at(want, cat[rows, i], dout[:, c0:c0 + d].astype(np.float64))
+        np.testing.assert_allclose(g[o:o + v * d].reshape(v, d), want, atol=1e-5)
+        c0 += d
+
+
+def test_out_of_range_index_gives_zero_row(gpu):
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    e = _embed_desc(_lib, [4], [3], [0])
+    tables = _dev.to_dev(np.arange(12, dtype=np.float32) + 1)
+    cat = _dev.to_dev(np.array([[1], [9], [-1]], np.int32), torch.int32)
+    out = _dev.empty((3, 4))
+    _lib.check(lib.agx_embed_concat_fwd(_dev.stream(), e, ptr(tables), None, 0, 0, None, 0, 0, ptr(cat), 1, 3, 0,
+                                        ptr(out), 4))
+    np.testing.assert_array_equal(out.cpu().numpy()[:, :3], [[4, 5, 6], [0, 0, 0], [0, 0, 0]])
+
+
+@pytest.mark.parametrize('B,G', [(1, 1), (12, 1076), (33, 4297)])
+def test_interp_aug_rownorm(gpu, B, G):
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    rs = np.random.RandomState(G)
+    real, fake = rs.randn(B, G).astype(np.float32), rs.randn(B, G).astype(np.float32)
+    alpha = rs.rand(B).astype(np.float32)
+    rd, fd = _dev.to_dev(real), _dev.to_dev(fake)
+    inter = _dev.empty((B, G))
+    _lib.check(lib.agx_gp_interp(_dev.stream(), ptr(rd), G, ptr(fd), G, ptr(_dev.to_dev(alpha)), ptr(inter), G, B, G))
+    np.testing.assert_array_equal(inter.cpu().numpy(), real + alpha[:, None] * (fake - real))
+    # augmentation: broadcast row and per-row noise
+    mask = rs.binomial(1, 0.5, B).astype(np.float32)
+    nf, nr = rs.randn(G).astype(np.float32), rs.randn(B, G).astype(np.float32)
+    _lib.check(lib.agx_aug_add(_dev.stream(), ptr(fd), G, ptr(_dev.to_dev(mask)), ptr(_dev.to_dev(nf)), G, 1, B, G))
+    _lib.check(lib.agx_aug_add(_dev.stream(), ptr(rd), G, ptr(_dev.to_dev(mask)), ptr(_dev.to_dev(nr)), G, 0, B, G))
+    np.testing.assert_array_equal(fd.cpu().numpy(), fake + mask[:, None] * nf[None, :])
+    np.testing.assert_array_equal(rd.cpu().numpy(), real + mask[:, None] * nr)
+    # slopes and the scaled gradient
+    g = rs.randn(B, G).astype(np.float32)
+    gd = _dev.to_dev(g)
+    slopes = _dev.empty(B)
+    coef = 10.0 * 2.0 / B
+    _lib.check(lib.agx_gp_rownorm_scale(_dev.stream(), ptr(gd), G, ptr(slopes), B, G, coef))
+    s = np.sqrt(np.sum(g.astype(np.float64) ** 2, axis=1))
+    np.testing.assert_allclose(slopes.cpu().numpy(), s, rtol=2e-6)
+    np.testing.assert_allclose(gd.cpu().numpy(), g * (coef * (s - 1) / s)[:, None], rtol=2e-5, atol=1e-7)
+
+
+def test_zero_slope_gives_nan_like_the_reference(gpu):
+    """sqrt has no epsilon (tf_utils.py:169): a zero gradient row yields NaN, not a silent 0."""
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    gd = _dev.zeros((2, 8))
+    gd[1] = 1.0
+    slopes = _dev.empty(2)
+    _lib.check(lib.agx_gp_rownorm_scale(_dev.stream(), ptr(gd), 8, ptr(slopes), 2, 8, 1.0))
+    out = gd.cpu().numpy()
+    assert np.all(np.isnan(out[0])) and np.all(np.isfinite(out[1]))
+
+
+def test_rowdot_delta_init_colsums_loss(gpu):
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    rs = np.random.RandomState(2)
+    B, H = 11, 100
+    R = 3 * B
+    A = rs.randn(R, H).astype(np.float32)
+    w = rs.randn(H).astype(np.float32)
+    b = np.array([0.3], np.float32)
+    Ad, wd = _dev.to_dev(A), _dev.to_dev(w)
+    out = _dev.empty(R)
+    _lib.check(lib.agx_rowdot(_dev.stream(), ptr(Ad), H, ptr(wd), ptr(_dev.to_dev(b)), ptr(out), R, H))
+    np.testing.assert_allclose(out.cpu().numpy(), A.astype(np.float64) @ w + 0.3, atol=2e-5)
+    d = _dev.empty((R, H))
+    inv = 1.0 / B
+    _lib.check(lib.agx_delta_init(_dev.stream(), ptr(Ad), H, ptr(wd), ptr(d), H, R, H, B, B, -inv, inv, 1.0, 0.1))
+    c = np.concatenate([np.full(B, -inv), np.full(B, inv), np.ones(B)]).astype(np.float32)
+    ref = np.where(A > 0, 1.0, 0.1) * (c[:, None] * w[None, :])
+    np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-6, atol=1e-9)
+    cs = _dev.empty(H)
+    _lib.check(lib.agx_colsum(_dev.stream(), ptr(Ad), H, 0, 2 * B, H, ptr(cs), 0))
+    np.testing.assert_allclose(cs.cpu().numpy(), A[:2 * B].astype(np.float64).sum(0), atol=2e-5)
+    cw, bo = _dev.empty(H), _dev.empty(1)
+    _lib.check(lib.agx_colsum_weighted(_dev.stream(), ptr(Ad), H, R, H, B, B, -inv, inv, 1.0, ptr(cw), ptr(bo)))
+    np.testing.assert_allclose(cw.cpu().numpy(), (c[:, None].astype(np.float64) * A).sum(0), atol=2e-5)
+    assert float(bo.item()) == 0.0
+    slopes = rs.rand(B).astype(np.float32) + 0.5
+    losses = _dev.empty(4)
+    _lib.check(lib.agx_wgan_loss(_dev.stream(), ptr(out), B, B, ptr(_dev.to_dev(slopes)), B, inv, 10.0, 1.0, ptr(losses)))
+    o = out.cpu().numpy().astype(np.float64)
+    wg = -o[:B].mean() + o[B:2 * B].mean()
+    gp = np.mean((slopes.astype(np.float64) - 1) ** 2)
+    np.testing.assert_allclose(losses.cpu().numpy()[:3], [wg, gp, wg + 10 * gp], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 1027, 4715587])
+def test_optimizers(gpu, n):
+    from adversarial_gene_expression_amd import ops, _dev
+    rs = np.random.RandomState(n % 97)
+    w0 = rs.randn(n).astype(np.float32)
+    g = (rs.randn(n) * 10.0 ** rs.uniform(-6, 0, n)).astype(np.float32)
+    g[::7] = 0.0
+    w, rms = _dev.to_dev(w0), _dev.zeros(n)
+    gd = _dev.to_dev(g)
+    ops.rmsprop(w, gd, rms, 5e-4)
+    ops.rmsprop(w, gd, rms, 5e-4)
+    g64, w64, r64 = g.astype(np.float64), w0.astype(np.float64), np.zeros(n)
+    for _ in range(2):
+        r64 = 0.9 * r64 + 0.1 * g64 * g64
+        w64 = w64 - 5e-4 * g64 / (np.sqrt(r64) + 1e-7)
+    np.testing.assert_allclose(rms.cpu().numpy(), r64, rtol=1e-5, atol=1e-30)
+    # update magnitude is <= lr*sqrt(10) per step; fp32 rounding of w dominates the error
+    np.testing.assert_allclose(w.cpu().numpy(), w64, rtol=0, atol=5e-7 + 1e-6 * np.abs(w64).max())
+    np.testing.assert_array_equal(w.cpu().numpy()[::7], w0[::7])   # zero gradient => untouched weight
+    w, m, v = _dev.to_dev(w0), _dev.zeros(n), _dev.zeros(n)
+    w64, m64, v64 = w0.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in (1, 2):
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam(w, gd, m, v, lr_t)
+        m64 = 0.9 * m64 + 0.1 * g64
+        v64 = 0.999 * v64 + 0.001 * g64 * g64
+        w64 = w64 - lr_t * m64 / (np.sqrt(v64) + 1e-7)
+    np.testing.assert_allclose(w.cpu().numpy(), w64, rtol=0, atol=5e-7 + 1e-6 * np.abs(w64).max())
+
+
+def test_rng_streams(gpu):
+    from adversarial_gene_expression_amd import ops
+    n = 1 << 20
+    a = ops.rng(n, 123, 0, True).cpu().numpy()
+    b = ops.rng(n, 123, 0, True).cpu().numpy()
+    c = ops.rng(n, 124, 0, True).cpu().numpy()
+    d = ops.rng(n, 123, n, True).cpu().numpy()
+    np.testing.assert_array_equal(a, b)                 # deterministic in (seed, offset)
+    assert not np.array_equal(a, c) and not np.array_equal(a, d)
+    assert abs(a.mean()) < 5e-3 and abs(a.std() - 1) < 5e-3 and np.all(np.isfinite(a))
+    assert abs(np.mean(a ** 4) - 3.0) < 0.05            # kurtosis of N(0,1)
+    u = ops.rng(n, 9, 0, False).cpu().numpy()
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 1e-3
+    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 5e-3
+    odd = ops.rng(5, 1, 0, True).cpu().numpy()           # ragged tail of a 4-wide counter block
+    assert np.all(np.isfinite(odd))
