@@ -37,6 +37,8 @@ class GemmDesc(C.Structure):
         ('ws_floats', C.c_int64),
         ('force_cfg', C.c_int32),
         ('force_splitk', C.c_int32),
+        ('prof_id', C.c_int32),
+        ('prof_tagged', C.c_int32),
     ]
 
 
@@ -89,6 +91,10 @@ SIGNATURES = {
     'agx_version': (C.c_int, []),
     'agx_last_error': (C.c_char_p, []),
     'agx_init': (C.c_int, [C.c_int]),
+    'agx_prof_enable': (C.c_int, [_i32]),
+    'agx_prof_reset': (C.c_int, []),
+    'agx_prof_read': (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'agx_prof_name': (C.c_char_p, [_i32]),
     'agx_gemm_f32': (C.c_int, [_vp, C.POINTER(GemmDesc)]),
     'agx_gemm_ws_floats': (_i64, [_i32, _i32, _i32]),
     'agx_embed_concat_fwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32,
@@ -111,6 +117,7 @@ SIGNATURES = {
     'agx_corr_xtx': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i64, _i64]),
     'agx_corr_num_tiles': (_i64, [_i32]),
     'agx_triu_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'agx_triu_pack_f64': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'agx_pearson_sums': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     'agx_gamma_sums': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     'agx_cgan_create': (C.c_int, [C.POINTER(CganConfig), C.POINTER(_vp)]),

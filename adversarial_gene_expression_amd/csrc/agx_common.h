@@ -11,6 +11,16 @@ namespace agx {
 void set_error(const char *fmt, ...);
 int num_cus();
 
+// In-stream event bracket around the launches of one kernel class (see agx_prof_* in agx.h).
+// Inactive (two loads, no HIP call) unless profiling is enabled for the class.
+struct ProfScope {
+  ProfScope(hipStream_t st, int id, double flops, double bytes);
+  ~ProfScope();
+  hipStream_t st_;
+  void *slot_;
+  hipEvent_t stop_;
+};
+
 #define AGX_CHECK_ARG(cond, ...)        \
   do {                                  \
     if (!(cond)) {                      \

@@ -154,6 +154,7 @@ struct Gemm {  // GEMM call builder
   Gemm &bias(const float *b) { g.bias = b; return *this; }
   Gemm &act() { g.act = 1; return *this; }
   Gemm &mask(const float *m, int ld) { g.mask = m; g.ldmask = ld; return *this; }
+  Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
   int run(hipStream_t st) { return agx_gemm_f32(st, &g); }
 };
 
@@ -170,7 +171,7 @@ int gen_forward(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat,
     float *o = last ? out : h->gh[l + 1];
     const int ldo_l = last ? ldo : h->ldgh[l + 1];
     Gemm g(h, in, ldin, 0, h->gp + m.w_off[l], m.ldw[l], 0, o, ldo_l, B, m.dims[l + 1], m.dims[l]);
-    g.bias(h->gp + m.b_off[l]);
+    g.bias(h->gp + m.b_off[l]).id(last ? AGX_K_GEN_FWD_OUT : AGX_K_GEN_FWD_HID);
     if (!last) g.act();
     AGX_TRY(g.run(st));
     in = o;
@@ -192,7 +193,7 @@ int disc_forward_rows(agx_cgan *h, hipStream_t st, const int32_t *cat, const flo
   for (int l = 0; l < L; ++l) {
     Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, h->A[l + 1], h->ldh[l + 1], R,
         m.dims[l + 1], m.dims[l]);
-    g.bias(h->dp + m.b_off[l]).act();
+    g.bias(h->dp + m.b_off[l]).act().id(l == 0 ? AGX_K_DISC_FWD_IN : AGX_K_DISC_FWD_HID);
     AGX_TRY(g.run(st));
     in = h->A[l + 1];
     ldin = h->ldh[l + 1];
@@ -209,7 +210,7 @@ int disc_backward_chain(agx_cgan *h, hipStream_t st, int R) {
     // D[l-1] = act'(A[l-1]) * (D[l] . W_{l-1}^T);  W_{l-1}: [d_{l-1}, d_l]
     Gemm g(h, h->D[l], h->ldh[l], 0, h->dp + m.w_off[l - 1], m.ldw[l - 1], 1, h->D[l - 1],
         h->ldh[l - 1], R, m.dims[l - 1], m.dims[l]);
-    g.mask(h->A[l - 1], h->ldh[l - 1]);
+    g.mask(h->A[l - 1], h->ldh[l - 1]).id(AGX_K_DISC_CHAIN);
     AGX_TRY(g.run(st));
   }
   return AGX_OK;
@@ -335,7 +336,7 @@ extern "C" int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_a
   AGX_TRY(disc_backward_chain(h, st, R));
   // g = d_1 . W_1[:G]^T  -> inter rows of X (inter itself is dead now)      :168
   AGX_TRY(Gemm(h, h->D[1] + (size_t)2 * B * h->ldh[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1,
-            Xi, ldx, B, G, m.dims[1]).run(st));
+            Xi, ldx, B, G, m.dims[1]).id(AGX_K_DISC_DX).run(st));
   // slopes, gp, dg = weight*(2/B)*(s-1)/s * g                                :169-170
   AGX_TRY(agx_gp_rownorm_scale(st, Xi, ldx, h->slopes, B, G, a->gp_weight * 2.0f * invb));
   AGX_TRY(agx_wgan_loss(st, h->out, B, B, h->slopes, B, invb, a->gp_weight, 1.f, a->losses));
@@ -349,7 +350,7 @@ extern "C" int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_a
     for (int l = 0; l < L; ++l) {
       float *Ai = h->A[l + 1] + (size_t)2 * B * h->ldh[l + 1];
       Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, Ai, h->ldh[l + 1], B, m.dims[l + 1], K);
-      g.mask(Ai, h->ldh[l + 1]);
+      g.mask(Ai, h->ldh[l + 1]).id(l == 0 ? AGX_K_GP2_IN : AGX_K_GP2_HID);
       AGX_TRY(g.run(st));
       in = Ai;
       ldin = h->ldh[l + 1];
@@ -364,13 +365,13 @@ extern "C" int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_a
     const float *in = l == 0 ? h->X : h->A[l];
     const int ldin = l == 0 ? ldx : h->ldh[l];
     AGX_TRY(Gemm(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l],
-              m.dims[l], m.dims[l + 1], R).run(st));
+              m.dims[l], m.dims[l + 1], R).id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID).run(st));
     AGX_TRY(agx_colsum(st, h->D[l + 1], h->ldh[l + 1], 0, 2 * B, m.dims[l + 1], h->dg + m.b_off[l], 0));
   }
   if (m.emb.n_cat > 0) {
     // d cov = D_1[0:2B] . W_1[G:, :]^T ; scatter-add into the tables
     AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0] + (size_t)G * m.ldw[0], m.ldw[0], 1,
-              h->dcov, h->ldcov, 2 * B, h->ncov, m.dims[1]).run(st));
+              h->dcov, h->ldcov, 2 * B, h->ncov, m.dims[1]).id(AGX_K_DISC_DCOV).run(st));
     AGX_TRY(agx_embed_bwd(st, &m.emb, h->dg, h->dcov, h->ldcov, m.n_num, a->cat, m.emb.n_cat, 2 * B,
                           B, 0));
   }
@@ -393,7 +394,8 @@ extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_ar
   AGX_TRY(agx_delta_init(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->D[L], h->ldh[L], B,
                          m.dims[L], B, 0, -invb, 0.f, 0.f, h->cfg.slope));
   AGX_TRY(disc_backward_chain(h, st, B));
-  AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1]).run(st));
+  AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1])
+              .id(AGX_K_DISC_DX).run(st));
 
   // generator backward
   const float *dout = dX;
@@ -402,18 +404,18 @@ extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_ar
     const float *in = l == 0 ? h->gin0 : h->gh[l];
     const int ldin = l == 0 ? h->ldg0 : h->ldgh[l];
     AGX_TRY(Gemm(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l],
-              gm.dims[l + 1], B).run(st));
+              gm.dims[l + 1], B).id(l == Lg ? AGX_K_GEN_DW_OUT : AGX_K_GEN_DW_HID).run(st));
     AGX_TRY(agx_colsum(st, dout, lddout, 0, B, gm.dims[l + 1], h->gg + gm.b_off[l], 0));
     if (l > 0) {
       Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
           gm.dims[l + 1]);
-      g.mask(h->gh[l], h->ldgh[l]);
+      g.mask(h->gh[l], h->ldgh[l]).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
       AGX_TRY(g.run(st));
       dout = h->gd[l];
       lddout = h->ldgh[l];
     } else if (gm.emb.n_cat > 0) {
       AGX_TRY(Gemm(h, dout, lddout, 0, h->gp + gm.w_off[0], gm.ldw[0], 1, h->gdin0, h->ldg0, B,
-                gm.dims[0], gm.dims[1]).run(st));
+                gm.dims[0], gm.dims[1]).id(AGX_K_GEN_BWD_HID).run(st));
       AGX_TRY(agx_embed_bwd(st, &gm.emb, h->gg, h->gdin0, h->ldg0, h->cfg.z_dim + gm.n_num, a->cat,
                             gm.emb.n_cat, B, 0, 0));
     }

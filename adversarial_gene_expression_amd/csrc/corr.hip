@@ -61,11 +61,12 @@ __global__ void __launch_bounds__(256) standardize_kernel(const float *__restric
 }
 
 // ---- condensed upper triangle with NaN dropping ---------------------------
-__global__ void __launch_bounds__(256) triu_count_kernel(const float *__restrict__ C, int ldc, int G,
+template <typename T>
+__global__ void __launch_bounds__(256) triu_count_kernel(const T *__restrict__ C, int ldc, int G,
                                                          long long *__restrict__ counts) {
   __shared__ int red[4];
   const int i = blockIdx.x;
-  const float *row = C + (size_t)i * ldc;
+  const T *row = C + (size_t)i * ldc;
   int n = 0;
   for (int j = i + 1 + threadIdx.x; j < G; j += blockDim.x) n += !isnan(row[j]);
   for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
@@ -104,17 +105,18 @@ __global__ void __launch_bounds__(1024) scan_kernel(const long long *__restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) triu_write_kernel(const float *__restrict__ C, int ldc, int G,
+template <typename T>
+__global__ void __launch_bounds__(256) triu_write_kernel(const T *__restrict__ C, int ldc, int G,
                                                          const long long *__restrict__ offsets,
-                                                         float *__restrict__ out) {
+                                                         T *__restrict__ out) {
   __shared__ int wtot[4];
   const int i = blockIdx.x;
-  const float *row = C + (size_t)i * ldc;
+  const T *row = C + (size_t)i * ldc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long base = offsets[i];
   for (int j0 = i + 1; j0 < G; j0 += 256) {
     const int j = j0 + threadIdx.x;
-    float v = 0.f;
+    T v = 0;
     bool keep = false;
     if (j < G) {
       v = row[j];
@@ -226,12 +228,14 @@ extern "C" int agx_standardize(void *stream, const float *x, int32_t ldx, int32_
   return AGX_OK;
 }
 
-extern "C" int agx_triu_pack(void *stream, const float *C, int32_t ldc, int32_t G, float *out,
-                             int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev) {
+namespace {
+template <typename T>
+int triu_pack_impl(void *stream, const T *C, int32_t ldc, int32_t G, T *out, int64_t *row_counts,
+                   int64_t *row_offsets, int64_t *n_out_dev) {
   AGX_CHECK_ARG(C && out && row_counts && row_offsets, "agx_triu_pack: null argument");
   AGX_CHECK_ARG(G > 0 && ldc >= G, "agx_triu_pack: bad shape");
   hipStream_t st = agx::as_stream(stream);
-  hipLaunchKernelGGL(triu_count_kernel, dim3(G), dim3(256), 0, st, C, ldc, G,
+  hipLaunchKernelGGL(triu_count_kernel<T>, dim3(G), dim3(256), 0, st, C, ldc, G,
                      reinterpret_cast<long long *>(row_counts));
   AGX_LAUNCH_CHECK();
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st,
@@ -239,10 +243,21 @@ extern "C" int agx_triu_pack(void *stream, const float *C, int32_t ldc, int32_t 
                      reinterpret_cast<long long *>(row_offsets),
                      reinterpret_cast<long long *>(n_out_dev));
   AGX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(triu_write_kernel, dim3(G), dim3(256), 0, st, C, ldc, G,
+  hipLaunchKernelGGL(triu_write_kernel<T>, dim3(G), dim3(256), 0, st, C, ldc, G,
                      reinterpret_cast<const long long *>(row_offsets), out);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
+}
+}  // namespace
+
+extern "C" int agx_triu_pack(void *stream, const float *C, int32_t ldc, int32_t G, float *out,
+                             int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev) {
+  return triu_pack_impl<float>(stream, C, ldc, G, out, row_counts, row_offsets, n_out_dev);
+}
+
+extern "C" int agx_triu_pack_f64(void *stream, const double *C, int32_t ldc, int32_t G, double *out,
+                                 int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev) {
+  return triu_pack_impl<double>(stream, C, ldc, G, out, row_counts, row_offsets, n_out_dev);
 }
 
 extern "C" int agx_pearson_sums(void *stream, const float *a, const float *b, int64_t n,

@@ -465,6 +465,7 @@ extern "C" int agx_opt_rmsprop(void *stream, float *w, const float *g, float *rm
   AGX_CHECK_ARG(agx::aligned16(w) && agx::aligned16(g) && agx::aligned16(rms),
                 "agx_opt_rmsprop: buffers must be 16-byte aligned");
   if (n == 0) return AGX_OK;
+  agx::ProfScope prof(agx::as_stream(stream), AGX_K_OPT_RMSPROP, 6.0 * n, 20.0 * n);
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n / 4 + 256, 256, 2048)), dim3(256), 0,
                      agx::as_stream(stream), w, g, rms, (long long)n, lr, rho, eps, grad_scale);
   AGX_LAUNCH_CHECK();
@@ -475,6 +476,7 @@ extern "C" int agx_opt_adam(void *stream, float *w, const float *g, float *m, fl
                             float lr_t, float beta1, float beta2, float eps, float grad_scale) {
   AGX_CHECK_ARG(w && g && m && v && n >= 0, "agx_opt_adam: bad argument");
   if (n == 0) return AGX_OK;
+  agx::ProfScope prof(agx::as_stream(stream), AGX_K_OPT_ADAM, 10.0 * n, 28.0 * n);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0,
                      agx::as_stream(stream), w, g, m, v, (long long)n, lr_t, beta1, beta2, eps,
                      grad_scale);

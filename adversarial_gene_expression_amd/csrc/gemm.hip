@@ -396,6 +396,9 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
   p.kchunk = pl.kchunk;
   const bool vec = agx::aligned16(g->A) && agx::aligned16(g->B) && (g->lda % 4 == 0) && (g->ldb % 4 == 0);
   hipStream_t st = agx::as_stream(stream);
+  agx::ProfScope prof(st, g->prof_tagged ? g->prof_id : AGX_K_GEMM_UNTAGGED,
+                      2.0 * g->M * (double)g->N * g->K,
+                      4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N));
   int rc;
   if (pl.cfg == 0)
     rc = launch_layout<128, 128, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
@@ -439,6 +442,10 @@ extern "C" int agx_corr_xtx(void *stream, const float *xs, int32_t ldx, int32_t 
   const bool vec = agx::aligned16(xs) && (ldx % 4 == 0);
   hipStream_t st = agx::as_stream(stream);
   const int tiles = (int)(tile_end - tile_begin);
+  // algorithmic work of the computed tiles: symmetric count N*G*(G+1) scaled by the tile share
+  const double share = (double)tiles / (double)total;
+  agx::ProfScope prof(st, AGX_K_CORR_XTX, share * (double)N * G * ((double)G + 1.0),
+                      4.0 * share * ((double)N * G + (double)G * G));
   return vec ? launch<128, 128, 2, 2, true, false, true, true>(st, p, tiles)
              : launch<128, 128, 2, 2, true, false, false, true>(st, p, tiles);
 }

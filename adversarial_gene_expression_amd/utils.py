@@ -115,12 +115,13 @@ def _r_from_sums(s, n):
 
 def _triu_pack_dev(c, ldc, g):
     lib = _lib.load()
-    out = _dev.empty(max(g * (g - 1) // 2, 1))
+    f64 = c.dtype == torch.float64
+    out = _dev.empty(max(g * (g - 1) // 2, 1), dtype=c.dtype)
     counts = _dev.empty(g + 1, dtype=torch.int64)
     offs = _dev.empty(g + 1, dtype=torch.int64)
     total = _dev.zeros(1, dtype=torch.int64)
-    _lib.check(lib.agx_triu_pack(_dev.stream(), ptr(c), ldc, g, ptr(out), ptr(counts), ptr(offs), ptr(total)),
-               'agx_triu_pack')
+    fn = lib.agx_triu_pack_f64 if f64 else lib.agx_triu_pack
+    _lib.check(fn(_dev.stream(), ptr(c), ldc, g, ptr(out), ptr(counts), ptr(offs), ptr(total)), 'agx_triu_pack')
     return out[:int(total.item())]
 
 
@@ -170,12 +171,15 @@ def pearson_correlation(x, y):
 def upper_diag_list(m_):
     """Condensed strict upper triangle, row-major, NaNs dropped.  Reference ``utils.py:837-849``."""
     dev_in = _is_dev(m_)
-    dt = _in_dtype(m_)
-    md, ld = _dev.padded_matrix(m_)
-    g = md.shape[0]
     if m_.shape[0] != m_.shape[1]:
         raise ValueError('upper_diag_list expects a square matrix')
-    return _out(_triu_pack_dev(md, ld, g), dev_in, dt)
+    g = m_.shape[0]
+    t = m_.tensor if isinstance(m_, DeviceArray) else m_
+    if (isinstance(t, np.ndarray) and t.dtype == np.float64) or (isinstance(t, torch.Tensor) and t.dtype == torch.float64):
+        md = _dev.to_dev(t, torch.float64)      # data movement only: stays float64, bit exact
+        return _out(_triu_pack_dev(md, md.stride(0), g), dev_in, np.float64)
+    md, ld = _dev.padded_matrix(m_)
+    return _out(_triu_pack_dev(md, ld, g), dev_in, np.float32)
 
 
 def correlations_list(x, y, corr_fn=pearson_correlation):

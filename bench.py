@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cGAN train samples/s at GTEx shape (18154 genes) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+
+A "step" is one iteration of the reference train loop (tf_utils.py:316-323): nb_critic=5
+critic steps (fresh z and alpha, same real batch) + 1 generator step on one batch, optimizer
+updates included, synthetic data resident in HBM.  Default workload = BASELINE.json configs[1]
+(GTEx-shaped cGAN, tissue+dataset covariates, batch 32 per GPU); for N > 1 the driver launches
+one rank per GPU with torch.distributed.run and the same per-GPU batch (weak scaling) with an
+RCCL all-reduce of the gradients per optimizer step.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     - the dominant kernel class of the timed region, timed live with HIP events on
+                 the launch stream (agx_prof_*), algorithmic bytes/FLOPs per launch over its
+                 mean duration, against the gfx950 peak (HBM 8 TB/s, fp32 MFMA 157.3 TFLOP/s)
+  cpu_baseline - the torch-CPU restatement of the same iteration (oracle/, kind "port": the
+                 reference's TF path cannot run offline) timed on this host's cores, N=1 only
+  secondary    - the same measurement at 512 samples/GPU (BASELINE.json configs[2] per-GPU
+                 shard, the MFMA-bound regime), N=1 only unless --secondary
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+WORKLOADS = {
+    # name: (G, vocab_sizes, n_num, h_dims, z_dim)
+    'gtex': (18154, [15, 3], 1, [256, 256], 64),          # gtex_tcga_gan.py:11-18, notebook shapes
+    'wide': (20000, [15, 3], 1, [1024, 1024], 64),        # BASELINE.json configs[4]
+    'ecoli': (4297, [6, 8, 5, 11, 5, 3, 5], 1, [128, 128], 10),
+}
+
+
+def algorithmic_flops_per_iter(G, V, n, H, Z, B, nb_critic=5):
+    """SURVEY.md section 8(d) formulas (two hidden layers)."""
+    E = sum(int(v ** 0.5) + 1 for v in V)
+    Dg, Dd = Z + n + E, G + n + E
+    H1, H2 = H
+    gen_fwd = 2 * B * (Dg * H1 + H1 * H2 + H2 * G)
+    disc_fwd = 2 * B * (Dd * H1 + H1 * H2 + H2)
+    gp_inp = 2 * B * (H1 * H2 + H1 * G)
+    bwd_w = 2 * B * (2 * H2 + 2 * H1 * H2 + Dd * H1)
+    gp_2nd = 2 * B * (2 * G * H1 + 2 * H1 * H2) + B * H2
+    critic = gen_fwd + 3 * disc_fwd + gp_inp + 2 * bwd_w + gp_2nd
+    disc_bwd_x = 2 * B * (H2 + H1 * H2 + G * H1)
+    gen_bwd = 2 * B * (2 * H2 * G + 2 * H1 * H2 + Dg * H1)
+    gen_step = gen_fwd + disc_fwd + disc_bwd_x + gen_bwd
+    return nb_critic * critic + gen_step
+
+
+def synthetic_batch_pool(G, V, n_num, rows, seed):
+    """X = F L + 0.5 eps, z-scored per gene, generated on the device; covariates uniform."""
+    import torch
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    f = torch.randn(rows, 32, device='cuda', generator=g)
+    l = torch.randn(32, G, device='cuda', generator=g)
+    x = f @ l + 0.5 * torch.randn(rows, G, device='cuda', generator=g)
+    x = (x - x.mean(0)) / x.std(0, unbiased=False)
+    cc = torch.stack([torch.randint(0, v, (rows,), device='cuda', generator=g) for v in V], 1).to(torch.int32)
+    nc = torch.zeros(rows, n_num, device='cuda')
+    return x.contiguous(), cc.contiguous(), nc
+
+
+def prof_read_all(lib, _lib):
+    out = {}
+    for k in range(64):
+        name = lib.agx_prof_name(k)
+        if not name:
+            break
+        ms, cnt, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.agx_prof_read(k, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl), ctypes.byref(by)))
+        if cnt.value:
+            out[k] = dict(name=name.decode(), ms=ms.value, count=cnt.value, flops=fl.value, bytes=by.value)
+    return out
+
+
+def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
+    import torch
+    import torch.distributed as dist
+    from adversarial_gene_expression_amd import _lib, tf_utils as T
+    lib = _lib.load()
+    G, V, n_num, H, Z = WORKLOADS[workload]
+    gen = T.Generator(G, V, n_num, H, Z, seed=1)
+    disc = T.Critic(G, V, n_num, H, 1, seed=2)
+    gopt, dopt = T.RMSprop(5e-4), T.RMSprop(5e-4)     # tf_utils.py:285-288
+    nbatches = 8
+    x, cc, nc = synthetic_batch_pool(G, V, n_num, B * nbatches, seed=100 + rank)
+    T.set_seed(1000 + rank)
+    Bg = B * world
+
+    def iteration(i):
+        s = slice((i % nbatches) * B, (i % nbatches + 1) * B)
+        xb, cb, nb = x[s], cc[s], nc[s]
+        for _ in range(nb_critic):
+            z = T.random_normal((B, Z))
+            al = T.random_uniform((B,))
+            T.train_disc(xb, z, cb, nb, gen, disc, dopt, alpha=al, batch_global=Bg)
+        z = T.random_normal((B, Z))
+        T.train_gen(z, cb, nb, gen, disc, gopt, batch_global=Bg)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(warmup):
+        iteration(i)
+    sync()
+    # discovery pass: which kernel class dominates?
+    lib.agx_prof_reset()
+    lib.agx_prof_enable(-1)
+    for i in range(3):
+        iteration(i)
+    torch.cuda.synchronize()
+    disc_prof = prof_read_all(lib, _lib)
+    dominant = max(disc_prof, key=lambda k: disc_prof[k]['ms'])
+    lib.agx_prof_reset()
+    lib.agx_prof_enable(dominant)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        iteration(i)
+    sync()
+    dt = time.perf_counter() - t0
+    lib.agx_prof_enable(-2)
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dom = prof_read_all(lib, _lib)[dominant]
+    lib.agx_prof_reset()
+    avg_s = dom['ms'] / dom['count'] * 1e-3
+    mfma_bound = B >= 256 and dom['name'] not in ('opt_rmsprop', 'opt_adam')
+    if mfma_bound:
+        ach = dom['flops'] / dom['count'] / avg_s / 1e12
+        roof = dict(bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TF)
+    else:
+        ach = dom['bytes'] / dom['count'] / avg_s / 1e9
+        roof = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS)
+    roof.update(kernel=dom['name'], launches=dom['count'], avg_us=avg_s * 1e6, traffic=measured_traffic(dom['name'], B))
+    tot = sum(v['ms'] for v in disc_prof.values())
+    breakdown = {v['name']: round(v['ms'] / 3 * 1e3, 1) for v in sorted(disc_prof.values(), key=lambda v: -v['ms'])}
+    flops_iter = algorithmic_flops_per_iter(G, V, n_num, H, Z, B, nb_critic) if len(H) == 2 else None
+    res = dict(value=Bg * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roof,
+               kernel_us_per_iter=breakdown, tagged_kernel_ms_per_iter=tot / 3,
+               whole_iter_tflops=(flops_iter / (dt / steps) / 1e12) if flops_iter else None,
+               whole_iter_mfma_frac=(flops_iter / (dt / steps) / 1e12 / MFMA_F32_PEAK_TF) if flops_iter else None)
+    del gen, disc, x
+    torch.cuda.empty_cache()
+    return res
+
+
+def measured_traffic(kernel, B):
+    """HBM bytes per launch from rocprofv3 PMC passes committed under profiles/ (None if absent)."""
+    p = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        return t.get('%s@B%d' % (kernel, B), {}).get('hbm_bytes_per_launch')
+    except Exception:
+        return None
+
+
+def cpu_baseline(workload, B, budget_s=15.0, nb_critic=5):
+    """torch-CPU fp32 restatement (oracle/cgan_oracle.py) of the same iteration on this host's cores."""
+    import torch
+    from oracle import cgan_oracle as O
+    G, V, n_num, H, Z = WORKLOADS[workload]
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    gp = O.to_torch(O.init_params('gen', G, V, n_num, H, Z, seed=1), dtype=torch.float32)
+    dp = O.to_torch(O.init_params('disc', G, V, n_num, H, seed=2), dtype=torch.float32)
+    go, do = O.RMSprop(5e-4), O.RMSprop(5e-4)
+    rs = np.random.RandomState(0)
+    x = torch.tensor(rs.randn(B, G), dtype=torch.float32)
+    cc = torch.tensor(np.stack([rs.randint(0, v, B) for v in V], 1))
+    nc = torch.zeros(B, n_num)
+
+    def iteration():
+        for _ in range(nb_critic):
+            O.train_disc(x, torch.randn(B, Z), cc, nc, gp, dp, do, torch.rand(B, 1))
+        O.train_gen(torch.randn(B, Z), cc, nc, gp, dp, go)
+
+    iteration()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        iteration()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 200:
+            break
+    return dict(value=B * n / el, unit='samples/s', cores=cores, kind='port',
+                sample='%d iterations (5 critic + 1 generator steps, batch %d, %s shape) of the torch-CPU fp32 '
+                       'restatement of tf_utils.py:186-258 in %.1f s; TensorFlow itself is unavailable offline'
+                       % (n, B, workload, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=32, help='samples per GPU per iteration')
+    ap.add_argument('--workload', default='gtex', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--secondary', dest='secondary', action='store_true', default=None)
+    ap.add_argument('--no-secondary', dest='secondary', action='store_false')
+    a = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if a.gpus != world and rank == 0 and world == 1 and a.gpus > 1:
+        print('bench.py: --gpus %d needs torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus), file=sys.stderr)
+        sys.exit(2)
+
+    res = run_gpu(a.workload, a.batch, a.steps, a.warmup, world, rank)
+    G, V, n_num, H, Z = WORKLOADS[a.workload]
+    line = {
+        'metric': 'cGAN train samples/sec at 18k genes', 'value': res['value'], 'unit': 'samples/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': res['ms_per_step'],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s cGAN train iteration (5 critic + 1 generator step, WGAN-GP, RMSprop), G=%d, '
+                               'covariates V=%s, h=%s, z=%d, batch %d per GPU'
+                               % ('GTEx-shaped' if a.workload == 'gtex' else a.workload, G, V, H, Z, a.batch),
+                   'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
+        'roofline': res['roofline'],
+        'kernel_us_per_iter': res['kernel_us_per_iter'],
+        'whole_iter_tflops': res['whole_iter_tflops'], 'whole_iter_mfma_frac': res['whole_iter_mfma_frac'],
+    }
+    want_secondary = a.secondary if a.secondary is not None else (world == 1 and a.batch != 512)
+    if want_secondary:
+        s = run_gpu(a.workload, 512, max(10, a.steps // 8), max(3, a.warmup // 4), world, rank)
+        line['secondary'] = {'workload': 'same network, 512 samples per GPU (BASELINE.json configs[2] per-GPU shard)',
+                             'value': s['value'], 'unit': 'samples/s', 'ms_per_step': s['ms_per_step'],
+                             'roofline': s['roofline'], 'kernel_us_per_iter': s['kernel_us_per_iter'],
+                             'whole_iter_tflops': s['whole_iter_tflops'],
+                             'whole_iter_mfma_frac': s['whole_iter_mfma_frac']}
+    if world == 1 and rank == 0 and not a.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(a.workload, a.batch)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

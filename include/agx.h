@@ -42,6 +42,24 @@ const char *agx_last_error(void);
 /* Select `device`, verify it is a gfx950 part, cache its CU count. */
 int agx_init(int device);
 
+/* ---- in-stream kernel timing (measurement only; no reference counterpart) ----
+ * When enabled, every launch site tagged with a kernel-class id brackets its launch(es)
+ * with a pair of HIP events on the SAME stream; agx_prof_read synchronises those events and
+ * returns the summed duration together with the algorithmic FLOPs / bytes of the launches
+ * (2*M*N*K and 4*(M*K + K*N + M*N) for a GEMM, 20 or 28 B/param for RMSprop / Adam).
+ * filter: -2 off (default), -1 every class, >= 0 that class only.                         */
+enum {
+  AGX_K_GEN_FWD_HID = 0, AGX_K_GEN_FWD_OUT, AGX_K_DISC_FWD_IN, AGX_K_DISC_FWD_HID,
+  AGX_K_DISC_CHAIN, AGX_K_DISC_DX, AGX_K_GP2_IN, AGX_K_GP2_HID, AGX_K_DISC_DW_IN,
+  AGX_K_DISC_DW_HID, AGX_K_DISC_DCOV, AGX_K_GEN_DW_OUT, AGX_K_GEN_DW_HID, AGX_K_GEN_BWD_OUT,
+  AGX_K_GEN_BWD_HID, AGX_K_OPT_RMSPROP, AGX_K_OPT_ADAM, AGX_K_CORR_XTX, AGX_K_GEMM_UNTAGGED,
+  AGX_K_COUNT
+};
+int agx_prof_enable(int32_t filter);
+int agx_prof_reset(void);
+int agx_prof_read(int32_t id, double *total_ms, int64_t *count, double *flops, double *bytes);
+const char *agx_prof_name(int32_t id);
+
 /* ---- dense layers: tf_utils.py:85-88, 132-135 (Dense+ReLU) and their
  *      autodiff (MatMul grads / BiasAddGrad / ReluGrad, tf_utils.py:220,255) -- */
 typedef struct agx_gemm {
@@ -65,6 +83,8 @@ typedef struct agx_gemm {
   int64_t ws_floats;
   int32_t force_cfg;    /* -1 auto; 0 = 128x128, 1 = 64x64, 2 = 32x128 tiles     */
   int32_t force_splitk; /* <=0 auto                                              */
+  int32_t prof_id;      /* AGX_K_* class for agx_prof_*; 0 with untagged = AGX_K_GEMM_UNTAGGED when prof_tagged == 0 */
+  int32_t prof_tagged;  /* 1 if prof_id is meaningful                            */
 } agx_gemm_t;
 int agx_gemm_f32(void *stream, const agx_gemm_t *p);
 /* Upper bound on the split-K scratch (floats) the heuristic may ask for. */
@@ -158,6 +178,9 @@ int64_t agx_corr_num_tiles(int32_t G);
  * row_counts/row_offsets: G+1 int64 scratch each; *n_out_dev receives the length.   */
 int agx_triu_pack(void *stream, const float *C, int32_t ldc, int32_t G, float *out,
                   int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev);
+/* Same for a float64 matrix (pure data movement: bit exact for either dtype). */
+int agx_triu_pack_f64(void *stream, const double *C, int32_t ldc, int32_t G, double *out,
+                      int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev);
 /* sums[0..4] (fp64) += sum a, sum b, sum a^2, sum b^2, sum ab over two fp32 vectors
  * transformed as (one_minus ? 1-v : v); the 1-D Pearson of utils.py:872 follows on host. */
 int agx_pearson_sums(void *stream, const float *a, const float *b, int64_t n, int32_t one_minus,

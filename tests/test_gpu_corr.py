@@ -21,6 +21,7 @@ def test_against_reference_goldens(gpu, name):
     from adversarial_gene_expression_amd import utils as U
     g = golden(name)
     x, y, y2 = g['x'], g['y'], g['y2']
+    # float64 inputs are computed in fp32 on the MFMA path (documented in utils.py): fp32 tolerance
     tol = 3e-6
     pxx = U.pearson_correlation(x, x)
     assert pxx.dtype == x.dtype and pxx.shape == g['pearson_xx'].shape

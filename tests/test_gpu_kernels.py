@@ -49,8 +49,8 @@ def test_embed_concat_fwd_bwd(gpu, B, row_mod):
     # backward: scatter-add (duplicates summed), untouched rows get exact zeros
     dout = rs.randn(B, width + 3).astype(np.float32)
     grad = _dev.to_dev(np.full(off, 7.0, np.float32))
-    _lib.check(lib.agx_embed_bwd(_dev.stream(), e, ptr(grad), ptr(_dev.to_dev(dout)), width + 3, 7, ptr(cd), 4, B,
-                                 row_mod, 0))
+    dd = _dev.to_dev(dout)
+    _lib.check(lib.agx_embed_bwd(_dev.stream(), e, ptr(grad), ptr(dd), width + 3, 7, ptr(cd), 4, B, row_mod, 0))
     g = grad.cpu().numpy()
     c0 = 7
     for i, (v, d, o) in enumerate(zip(vocab, edim, offs)):
@@ -81,13 +81,15 @@ def test_interp_aug_rownorm(gpu, B, G):
     alpha = rs.rand(B).astype(np.float32)
     rd, fd = _dev.to_dev(real), _dev.to_dev(fake)
     inter = _dev.empty((B, G))
-    _lib.check(lib.agx_gp_interp(_dev.stream(), ptr(rd), G, ptr(fd), G, ptr(_dev.to_dev(alpha)), ptr(inter), G, B, G))
+    ad = _dev.to_dev(alpha)   # keep every device buffer referenced until its kernel has been enqueued
+    _lib.check(lib.agx_gp_interp(_dev.stream(), ptr(rd), G, ptr(fd), G, ptr(ad), ptr(inter), G, B, G))
     np.testing.assert_array_equal(inter.cpu().numpy(), real + alpha[:, None] * (fake - real))
     # augmentation: broadcast row and per-row noise
     mask = rs.binomial(1, 0.5, B).astype(np.float32)
     nf, nr = rs.randn(G).astype(np.float32), rs.randn(B, G).astype(np.float32)
-    _lib.check(lib.agx_aug_add(_dev.stream(), ptr(fd), G, ptr(_dev.to_dev(mask)), ptr(_dev.to_dev(nf)), G, 1, B, G))
-    _lib.check(lib.agx_aug_add(_dev.stream(), ptr(rd), G, ptr(_dev.to_dev(mask)), ptr(_dev.to_dev(nr)), G, 0, B, G))
+    md, nfd, nrd = _dev.to_dev(mask), _dev.to_dev(nf), _dev.to_dev(nr)
+    _lib.check(lib.agx_aug_add(_dev.stream(), ptr(fd), G, ptr(md), ptr(nfd), G, 1, B, G))
+    _lib.check(lib.agx_aug_add(_dev.stream(), ptr(rd), G, ptr(md), ptr(nrd), G, 0, B, G))
     np.testing.assert_array_equal(fd.cpu().numpy(), fake + mask[:, None] * nf[None, :])
     np.testing.assert_array_equal(rd.cpu().numpy(), real + mask[:, None] * nr)
     # slopes and the scaled gradient
@@ -124,7 +126,8 @@ def test_rowdot_delta_init_colsums_loss(gpu):
     b = np.array([0.3], np.float32)
     Ad, wd = _dev.to_dev(A), _dev.to_dev(w)
     out = _dev.empty(R)
-    _lib.check(lib.agx_rowdot(_dev.stream(), ptr(Ad), H, ptr(wd), ptr(_dev.to_dev(b)), ptr(out), R, H))
+    bd = _dev.to_dev(b)
+    _lib.check(lib.agx_rowdot(_dev.stream(), ptr(Ad), H, ptr(wd), ptr(bd), ptr(out), R, H))
     np.testing.assert_allclose(out.cpu().numpy(), A.astype(np.float64) @ w + 0.3, atol=2e-5)
     d = _dev.empty((R, H))
     inv = 1.0 / B
@@ -141,7 +144,8 @@ def test_rowdot_delta_init_colsums_loss(gpu):
     assert float(bo.item()) == 0.0
     slopes = rs.rand(B).astype(np.float32) + 0.5
     losses = _dev.empty(4)
-    _lib.check(lib.agx_wgan_loss(_dev.stream(), ptr(out), B, B, ptr(_dev.to_dev(slopes)), B, inv, 10.0, 1.0, ptr(losses)))
+    sd = _dev.to_dev(slopes)
+    _lib.check(lib.agx_wgan_loss(_dev.stream(), ptr(out), B, B, ptr(sd), B, inv, 10.0, 1.0, ptr(losses)))
     o = out.cpu().numpy().astype(np.float64)
     wg = -o[:B].mean() + o[B:2 * B].mean()
     gp = np.mean((slopes.astype(np.float64) - 1) ** 2)
