@@ -33,6 +33,9 @@ class GemmDesc(C.Structure):
         ('mask', C.c_void_p),
         ('ldmask', C.c_int32),
         ('accumulate', C.c_int32),
+        ('rowscale', C.c_void_p),
+        ('rowsq', C.c_void_p),
+        ('rowsq_ld', C.c_int32),
         ('ws', C.c_void_p),
         ('ws_floats', C.c_int64),
         ('force_cfg', C.c_int32),
@@ -84,6 +87,18 @@ class StepArgs(C.Structure):
     ]
 
 
+class IterArgs(C.Structure):
+    _fields_ = [
+        ('B', C.c_int32), ('nb_critic', C.c_int32),
+        ('gp_weight', C.c_float),
+        ('lr_disc', C.c_float), ('lr_gen', C.c_float), ('rho', C.c_float), ('eps', C.c_float),
+        ('disc_rms', C.c_void_p), ('gen_rms', C.c_void_p),
+        ('seed', C.c_uint64),
+        ('aug_mask_disc', C.c_void_p), ('aug_noise_fake', C.c_void_p), ('aug_noise_real', C.c_void_p),
+        ('aug_mask_gen', C.c_void_p), ('aug_noise_gen', C.c_void_p),
+    ]
+
+
 _vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); every symbol include/agx.h declares
@@ -95,6 +110,9 @@ SIGNATURES = {
     'agx_prof_reset': (C.c_int, []),
     'agx_prof_read': (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'agx_prof_name': (C.c_char_p, [_i32]),
+    'agx_prof_spin': (C.c_int, [_vp, _i32]),
+    'agx_prof_enabled': (C.c_int, []),
+    'agx_prof_clock': (C.c_int, [_vp, _i32, _i32, _vp]),
     'agx_gemm_f32': (C.c_int, [_vp, C.POINTER(GemmDesc)]),
     'agx_gemm_ws_floats': (_i64, [_i32, _i32, _i32]),
     'agx_embed_concat_fwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32,
@@ -104,6 +122,8 @@ SIGNATURES = {
     'agx_aug_add': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32]),
     'agx_rowdot': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32]),
     'agx_delta_init': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32]),
+    'agx_critic_head': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32]),
+    'agx_gp_finalize': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32]),
     'agx_gp_rownorm_scale': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32]),
     'agx_wgan_loss': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _f32, _f32, _vp]),
     'agx_colsum': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32]),
@@ -112,6 +132,8 @@ SIGNATURES = {
     'agx_opt_adam': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32]),
     'agx_rng_normal': (C.c_int, [_vp, _vp, _i64, _u64, _u64]),
     'agx_rng_uniform': (C.c_int, [_vp, _vp, _i64, _u64, _u64]),
+    'agx_rng_at': (C.c_int, [_vp, _vp, _i64, _u64, _vp, _u64, _i32]),
+    'agx_set_u64': (C.c_int, [_vp, _vp, _u64]),
     'agx_colstats': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     'agx_standardize': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
     'agx_corr_xtx': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i64, _i64]),
@@ -128,6 +150,10 @@ SIGNATURES = {
     'agx_cgan_disc_forward': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     'agx_cgan_disc_grads': (C.c_int, [_vp, _vp, C.POINTER(StepArgs)]),
     'agx_cgan_gen_grads': (C.c_int, [_vp, _vp, C.POINTER(StepArgs)]),
+    'agx_cgan_iter_capture': (C.c_int, [_vp, _vp, C.POINTER(IterArgs), C.POINTER(_vp)]),
+    'agx_cgan_iter_launch': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _u64, _vp]),
+    'agx_cgan_iter_rng_draws': (_i64, [_vp]),
+    'agx_cgan_iter_destroy': (C.c_int, [_vp]),
 }
 
 _lib = None

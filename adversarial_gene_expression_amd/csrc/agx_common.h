@@ -10,6 +10,7 @@ namespace agx {
 
 void set_error(const char *fmt, ...);
 int num_cus();
+int gemm_prepare_device();
 
 // In-stream event bracket around the launches of one kernel class (see agx_prof_* in agx.h).
 // Inactive (two loads, no HIP call) unless profiling is enabled for the class.

@@ -38,11 +38,18 @@ struct agx_cgan {
   float *D[AGX_MAX_LAYERS + 1] = {};        // critic deltas       [3Bm, ldh]
   int ldh[AGX_MAX_LAYERS + 1] = {};
   float *out = nullptr, *slopes = nullptr;  // [3Bm], [Bm]
+  float *fscale = nullptr, *rowsq = nullptr;  // [Bm], [Bm, nslab]
+  int nslab = 0;
   float *dcov = nullptr;                    // [2Bm, ldcov]
   float *gin0 = nullptr, *gdin0 = nullptr;  // [Bm, ldg0]
   float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [Bm, ldgh]
   float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas
   int ldgh[AGX_MAX_LAYERS + 1] = {};
+  // staging for the captured iteration (agx_cgan_iter_*)
+  float *sx = nullptr, *snum = nullptr, *zbuf = nullptr, *abuf = nullptr, *losslog = nullptr;
+  int32_t *scat = nullptr;
+  uint64_t *rngpos = nullptr;
+  int ldsx = 0;
   float *skws = nullptr;                    // split-K scratch
   int64_t skws_floats = 0;
   int64_t ws_floats_total = 0;
@@ -103,6 +110,9 @@ void carve(agx_cgan *h, float *base) {
   }
   h->out = cv.take(3 * Bm);
   h->slopes = cv.take(Bm);
+  h->fscale = cv.take(Bm);
+  h->nslab = (c.x_dim + 31) / 32;
+  h->rowsq = cv.take((int64_t)Bm * h->nslab);
   h->dcov = cv.take((int64_t)2 * Bm * h->ldcov);
   h->gin0 = cv.take((int64_t)Bm * h->ldg0);
   h->gdin0 = cv.take((int64_t)Bm * h->ldg0);
@@ -112,6 +122,14 @@ void carve(agx_cgan *h, float *base) {
     h->gh[l] = cv.take((int64_t)Bm * h->ldgh[l]);
     h->gd[l] = cv.take((int64_t)Bm * h->ldgh[l]);
   }
+  h->ldsx = r4(c.x_dim);
+  h->sx = cv.take((int64_t)Bm * h->ldsx);
+  h->snum = cv.take((int64_t)Bm * std::max(c.gen.n_num, 1));
+  h->scat = reinterpret_cast<int32_t *>(cv.take((int64_t)Bm * std::max(c.gen.emb.n_cat, 1)));
+  h->zbuf = cv.take((int64_t)Bm * c.z_dim);
+  h->abuf = cv.take(Bm);
+  h->losslog = cv.take(4 * 64);
+  h->rngpos = reinterpret_cast<uint64_t *>(cv.take(16));
   // split-K scratch: the largest request over the GEMM shapes of both steps
   int64_t need = 0;
   const int Bs[2] = {Bm, std::min(Bm, 32)};
@@ -154,6 +172,8 @@ struct Gemm {  // GEMM call builder
   Gemm &bias(const float *b) { g.bias = b; return *this; }
   Gemm &act() { g.act = 1; return *this; }
   Gemm &mask(const float *m, int ld) { g.mask = m; g.ldmask = ld; return *this; }
+  Gemm &rowscale(const float *r) { g.rowscale = r; return *this; }
+  Gemm &rowsq(float *q, int ld) { g.rowsq = q; g.rowsq_ld = ld; return *this; }
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
   int run(hipStream_t st) { return agx_gemm_f32(st, &g); }
 };
@@ -183,7 +203,7 @@ int gen_forward(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat,
 // critic forward over R rows of h->X (gene columns already in place); fills covariate
 // columns (source rows modulo B), activations A[1..L] and scores out[R]
 int disc_forward_rows(agx_cgan *h, hipStream_t st, const int32_t *cat, const float *num, int R,
-                      int B) {
+                      int B, int n0, int n1, float c0, float c1, float c2) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   const int L = m.n_layers - 1;
   AGX_TRY(agx_embed_concat_fwd(st, &m.emb, h->dp, nullptr, 0, 0, num, m.n_num, m.n_num, cat,
@@ -198,8 +218,9 @@ int disc_forward_rows(agx_cgan *h, hipStream_t st, const int32_t *cat, const flo
     in = h->A[l + 1];
     ldin = h->ldh[l + 1];
   }
-  return agx_rowdot(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->dp + m.b_off[L], h->out, R,
-                    m.dims[L]);
+  // Dense(1) + seed of the backward chain D[L] = act'(A_L) * c(r) * w_out
+  return agx_critic_head(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->dp + m.b_off[L], h->out,
+                         h->D[L], h->ldh[L], R, m.dims[L], n0, n1, c0, c1, c2, h->cfg.slope);
 }
 
 // first-order chain D[L] -> D[1] over R rows
@@ -306,7 +327,7 @@ extern "C" int agx_cgan_disc_forward(agx_cgan_t *h, void *stream, const float *x
   hipStream_t st = agx::as_stream(stream);
   AGX_HIP(hipMemcpy2DAsync(h->X, (size_t)h->ldx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
                            hipMemcpyDeviceToDevice, st));
-  AGX_TRY(disc_forward_rows(h, st, cat, num, B, 0));
+  AGX_TRY(disc_forward_rows(h, st, cat, num, B, 0, B, 0, 0.f, 0.f, 0.f));
   AGX_HIP(hipMemcpyAsync(scores, h->out, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
   return AGX_OK;
 }
@@ -328,20 +349,19 @@ extern "C" int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_a
     AGX_TRY(agx_aug_add(st, Xr, ldx, a->aug_mask, a->aug_noise_real, G, 0, B, G));
   }
   AGX_TRY(agx_gp_interp(st, Xr, ldx, Xf, ldx, a->alpha, Xi, ldx, B, G));  // :162-164
-  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, R, B));                // :213-214, :167
-
-  // seed + first-order chain
-  AGX_TRY(agx_delta_init(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->D[L], h->ldh[L], R,
-                         m.dims[L], B, B, -invb, invb, 1.f, h->cfg.slope));
+  // one forward over [real; fake; inter] (:213-214, :167) + seed c = [-1/B | +1/B | 1]
+  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, R, B, B, B, -invb, invb, 1.f));
   AGX_TRY(disc_backward_chain(h, st, R));
-  // g = d_1 . W_1[:G]^T  -> inter rows of X (inter itself is dead now)      :168
-  AGX_TRY(Gemm(h, h->D[1] + (size_t)2 * B * h->ldh[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1,
-            Xi, ldx, B, G, m.dims[1]).id(AGX_K_DISC_DX).run(st));
-  // slopes, gp, dg = weight*(2/B)*(s-1)/s * g                                :169-170
-  AGX_TRY(agx_gp_rownorm_scale(st, Xi, ldx, h->slopes, B, G, a->gp_weight * 2.0f * invb));
+  // g = d_1 . W_1[:G]^T -> inter rows of X (inter itself is dead now), with the per-slab
+  // row sums of squares as a side output of the epilogue                    :168-169
+  float *D1i = h->D[1] + (size_t)2 * B * h->ldh[1];
+  AGX_TRY(Gemm(h, D1i, h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, Xi, ldx, B, G, m.dims[1])
+              .rowsq(h->rowsq, h->nslab).id(AGX_K_DISC_DX).run(st));
+  // slopes; f = weight*(2/B)*(s-1)/s; D_1[inter] *= f (dg = f*g stays implicit); the penalty has
+  // no gradient w.r.t. the covariate rows of W_1: zero those columns of the inter rows   :169-170
+  AGX_TRY(agx_gp_finalize(st, h->rowsq, h->nslab, h->nslab, h->slopes, h->fscale, D1i, h->ldh[1],
+                          m.dims[1], Xi + G, ldx, h->ncov, B, a->gp_weight * 2.0f * invb));
   AGX_TRY(agx_wgan_loss(st, h->out, B, B, h->slopes, B, invb, a->gp_weight, 1.f, a->losses));
-  if (h->ncov > 0)  // the penalty has no gradient w.r.t. the covariate rows of W_1
-    AGX_HIP(hipMemset2DAsync(Xi + G, (size_t)ldx * 4, 0, (size_t)h->ncov * 4, B, st));
 
   // second-order chain, in place over the inter rows of the activations
   {
@@ -351,6 +371,7 @@ extern "C" int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_a
       float *Ai = h->A[l + 1] + (size_t)2 * B * h->ldh[l + 1];
       Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, Ai, h->ldh[l + 1], B, m.dims[l + 1], K);
       g.mask(Ai, h->ldh[l + 1]).id(l == 0 ? AGX_K_GP2_IN : AGX_K_GP2_HID);
+      if (l == 0) g.rowscale(h->fscale);  // e_1 = relu'(A_1) * ((f*g) . W_1[:G])
       AGX_TRY(g.run(st));
       in = Ai;
       ldin = h->ldh[l + 1];
@@ -382,17 +403,15 @@ extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_ar
   AGX_TRY(check_step(h, a, false));
   hipStream_t st = agx::as_stream(stream);
   const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
-  const int L = m.n_layers - 1, Lg = gm.n_layers - 1, B = a->B, G = h->G, ldx = h->ldx;
+  const int Lg = gm.n_layers - 1, B = a->B, G = h->G, ldx = h->ldx;
   const float invb = 1.0f / (float)a->B_global;
   float *Xg = h->X, *dX = h->X + (size_t)B * ldx;
 
   AGX_TRY(gen_forward(h, st, a->z, a->cat, a->num, B, Xg, ldx));                    // :244
   if (a->aug_mask) AGX_TRY(agx_aug_add(st, Xg, ldx, a->aug_mask, a->aug_noise_fake, G, 0, B, G));  // :247
-  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, B, 0));                          // :250
+  // critic forward (:250) + seed -1/B of d mean(-D)/d out; critic weights untouched   :255
+  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, B, 0, B, 0, -invb, 0.f, 0.f));
   AGX_TRY(agx_wgan_loss(st, h->out, B, 0, nullptr, 0, invb, 0.f, 1.f, a->losses));  // :253
-  // back through the critic to its input (critic weights untouched)               :255
-  AGX_TRY(agx_delta_init(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->D[L], h->ldh[L], B,
-                         m.dims[L], B, 0, -invb, 0.f, 0.f, h->cfg.slope));
   AGX_TRY(disc_backward_chain(h, st, B));
   AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1])
               .id(AGX_K_DISC_DX).run(st));
@@ -419,6 +438,128 @@ extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_ar
       AGX_TRY(agx_embed_bwd(st, &gm.emb, h->gg, h->gdin0, h->ldg0, h->cfg.z_dim + gm.n_num, a->cat,
                             gm.emb.n_cat, B, 0, 0));
     }
+  }
+  return AGX_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// one loop iteration as a hipGraph
+// ---------------------------------------------------------------------------
+struct agx_iter_graph {
+  agx_cgan *h = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int B = 0, nb_critic = 0;
+  int64_t draws = 0;
+};
+
+namespace {
+inline uint64_t r4u(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
+
+int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int64_t *draws) {
+  const int B = a->B, Z = h->cfg.z_dim;
+  uint64_t sub = 0;
+  agx_step_args_t s;
+  memset(&s, 0, sizeof(s));
+  s.x = h->sx; s.ldx = h->ldsx; s.z = h->zbuf; s.cat = h->scat; s.num = h->snum; s.alpha = h->abuf;
+  s.B = B; s.B_global = B; s.gp_weight = a->gp_weight;
+  for (int k = 0; k < a->nb_critic; ++k) {
+    AGX_TRY(agx_rng_at(st, h->zbuf, (int64_t)B * Z, a->seed, h->rngpos, sub, 1));
+    sub += r4u((uint64_t)B * Z);
+    AGX_TRY(agx_rng_at(st, h->abuf, B, a->seed, h->rngpos, sub, 0));
+    sub += r4u((uint64_t)B);
+    s.aug_mask = a->aug_mask_disc; s.aug_noise_fake = a->aug_noise_fake; s.aug_noise_real = a->aug_noise_real;
+    s.losses = h->losslog + 4 * k;
+    AGX_TRY(agx_cgan_disc_grads(h, st, &s));
+    AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
+  }
+  AGX_TRY(agx_rng_at(st, h->zbuf, (int64_t)B * Z, a->seed, h->rngpos, sub, 1));
+  sub += r4u((uint64_t)B * Z);
+  s.aug_mask = a->aug_mask_gen; s.aug_noise_fake = a->aug_noise_gen; s.aug_noise_real = nullptr;
+  s.losses = h->losslog + 4 * a->nb_critic;
+  AGX_TRY(agx_cgan_gen_grads(h, st, &s));
+  AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
+  *draws = (int64_t)sub;
+  return AGX_OK;
+}
+}  // namespace
+
+extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter_args_t *a,
+                                     agx_iter_graph_t **out) {
+  AGX_CHECK_ARG(h && a && out, "agx_cgan_iter_capture: null argument");
+  if (!h->bound) { agx::set_error("agx_cgan_iter_capture: not bound"); return AGX_E_STATE; }
+  AGX_CHECK_ARG(a->B > 0 && a->B <= h->Bm, "agx_cgan_iter_capture: batch %d outside (0, %d]", a->B, h->Bm);
+  AGX_CHECK_ARG(a->nb_critic >= 0 && a->nb_critic < 63, "agx_cgan_iter_capture: nb_critic %d", a->nb_critic);
+  AGX_CHECK_ARG(a->disc_rms && a->gen_rms, "agx_cgan_iter_capture: optimizer slots missing");
+  AGX_CHECK_ARG(!a->aug_mask_disc || (a->aug_noise_fake && a->aug_noise_real), "agx_cgan_iter_capture: critic aug noise missing");
+  AGX_CHECK_ARG(!a->aug_mask_gen || a->aug_noise_gen, "agx_cgan_iter_capture: generator aug noise missing");
+  AGX_CHECK_ARG(stream != nullptr, "agx_cgan_iter_capture: capture needs a non-default stream");
+  if (agx_prof_enabled()) {
+    agx::set_error("agx_cgan_iter_capture: event brackets cannot be captured; call agx_prof_enable(-2) first");
+    return AGX_E_STATE;
+  }
+  hipStream_t st = agx::as_stream(stream);
+  agx_iter_graph *g = new (std::nothrow) agx_iter_graph();
+  AGX_CHECK_ARG(g, "agx_cgan_iter_capture: out of host memory");
+  g->h = h; g->B = a->B; g->nb_critic = a->nb_critic;
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) {
+    delete g;
+    agx::set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+    return AGX_E_HIP;
+  }
+  int rc = record_iteration(h, st, a, &g->draws);
+  e = hipStreamEndCapture(st, &g->graph);
+  if (rc != AGX_OK) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return rc;
+  }
+  if (e != hipSuccess || !g->graph) {
+    delete g;
+    agx::set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    return AGX_E_HIP;
+  }
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    agx::set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return AGX_E_HIP;
+  }
+  *out = g;
+  return AGX_OK;
+}
+
+extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
+                                    const int32_t *cat, const float *num, uint64_t rng_offset,
+                                    float *losses_out) {
+  AGX_CHECK_ARG(g && g->exec && x, "agx_cgan_iter_launch: null argument");
+  agx_cgan *h = g->h;
+  AGX_CHECK_ARG(ldx >= h->G, "agx_cgan_iter_launch: ldx < x_dim");
+  hipStream_t st = agx::as_stream(stream);
+  const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
+  AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_launch: covariates missing");
+  AGX_HIP(hipMemcpy2DAsync(h->sx, (size_t)h->ldsx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
+                           hipMemcpyDeviceToDevice, st));
+  if (ncat) AGX_HIP(hipMemcpyAsync(h->scat, cat, (size_t)B * ncat * 4, hipMemcpyDeviceToDevice, st));
+  if (nnum) AGX_HIP(hipMemcpyAsync(h->snum, num, (size_t)B * nnum * 4, hipMemcpyDeviceToDevice, st));
+  AGX_TRY(agx_set_u64(st, h->rngpos, rng_offset));
+  AGX_HIP(hipGraphLaunch(g->exec, st));
+  if (losses_out)
+    AGX_HIP(hipMemcpyAsync(losses_out, h->losslog, (size_t)(g->nb_critic + 1) * 4 * sizeof(float),
+                           hipMemcpyDeviceToDevice, st));
+  return AGX_OK;
+}
+
+extern "C" int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g) { return g ? g->draws : 0; }
+
+extern "C" int agx_cgan_iter_destroy(agx_iter_graph_t *g) {
+  if (g) {
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
   }
   return AGX_OK;
 }

@@ -134,6 +134,61 @@ __global__ void __launch_bounds__(256) delta_init_kernel(const float *__restrict
   }
 }
 
+// fused Dense(1) forward + backward seed: one wave per row
+__global__ void __launch_bounds__(256) critic_head_kernel(const float *__restrict__ A, int lda,
+                                                          const float *__restrict__ w,
+                                                          const float *__restrict__ b,
+                                                          float *__restrict__ out,
+                                                          float *__restrict__ delta, int ldd, int R,
+                                                          int H, int n0, int n1, float c0, float c1,
+                                                          float c2, float slope) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float *a = A + (size_t)row * lda;
+  float *d = delta + (size_t)row * ldd;
+  const float c = row < n0 ? c0 : (row < n0 + n1 ? c1 : c2);
+  float s = 0.f;
+  for (int j = lane; j < H; j += 64) {
+    const float av = a[j], wv = w[j];
+    s += av * wv;
+    const float v = c * wv;
+    d[j] = av > 0.f ? v : v * slope;
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s + b[0];
+}
+
+// gradient-penalty finalisation, one block per interpolated row b:
+//   s = sqrt(sum of the per-slab partials) (no epsilon, tf_utils.py:169); f = coef*(s-1)/s;
+//   slopes[b] = s; fscale[b] = f; d1[b,:] *= f; xcov[b, 0:ncov] = 0
+__global__ void __launch_bounds__(256) gp_finalize_kernel(const float *__restrict__ rowsq,
+                                                          int rowsq_ld, int nslab,
+                                                          float *__restrict__ slopes,
+                                                          float *__restrict__ fscale,
+                                                          float *__restrict__ d1, int ldd, int H1,
+                                                          float *__restrict__ xcov, int ldx, int ncov,
+                                                          float coef) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float *q = rowsq + (size_t)b * rowsq_ld;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < nslab; j += blockDim.x) s += q[j];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float sl = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  const float f = coef * (sl - 1.f) / sl;  // sl == 0 -> -inf, propagates NaN like the reference
+  if (threadIdx.x == 0) {
+    slopes[b] = sl;
+    fscale[b] = f;
+  }
+  float *d = d1 + (size_t)b * ldd;
+  for (int j = threadIdx.x; j < H1; j += blockDim.x) d[j] = d[j] * f;
+  float *xc = xcov + (size_t)b * ldx;
+  for (int j = threadIdx.x; j < ncov; j += blockDim.x) xc[j] = 0.f;
+}
+
 // one block per row: s = ||g||_2 ; g *= coef*(s-1)/s
 __global__ void __launch_bounds__(256) gp_rownorm_scale_kernel(float *__restrict__ g, int ldg,
                                                                float *__restrict__ slopes, int G,
@@ -297,10 +352,14 @@ __device__ __forceinline__ float u01(unsigned x) {  // [0,1) with 24 random bits
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
+__global__ void set_u64_kernel(unsigned long long *dst, unsigned long long v) { *dst = v; }
+
 template <bool NORMAL>
 __global__ void __launch_bounds__(256) rng_kernel(float *__restrict__ out, long long n,
                                                   unsigned long long seed,
-                                                  unsigned long long offset) {
+                                                  unsigned long long offset,
+                                                  const unsigned long long *__restrict__ base_dev) {
+  if (base_dev) offset += *base_dev;  // device-resident stream position (graph replay)
   // counter block q produces elements 4q .. 4q+3 of the (seed, offset)-keyed stream
   const long long nq = (n + 3) >> 2;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
@@ -418,6 +477,31 @@ extern "C" int agx_delta_init(void *stream, const float *A, int32_t lda, const f
   return AGX_OK;
 }
 
+extern "C" int agx_critic_head(void *stream, const float *A, int32_t lda, const float *w,
+                               const float *b, float *out, float *delta, int32_t ldd, int32_t R,
+                               int32_t H, int32_t n0, int32_t n1, float c0, float c1, float c2,
+                               float slope) {
+  AGX_CHECK_ARG(A && w && b && out && delta && lda >= H && ldd >= H, "agx_critic_head: bad argument");
+  if (R <= 0 || H <= 0) return AGX_OK;
+  hipLaunchKernelGGL(critic_head_kernel, dim3(agx::cdiv(R, 4)), dim3(256), 0, agx::as_stream(stream),
+                     A, lda, w, b, out, delta, ldd, R, H, n0, n1, c0, c1, c2, slope);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_gp_finalize(void *stream, const float *rowsq, int32_t rowsq_ld, int32_t nslab,
+                               float *slopes, float *fscale, float *d1, int32_t ldd, int32_t H1,
+                               float *xcov, int32_t ldx, int32_t ncov, int32_t B, float coef) {
+  AGX_CHECK_ARG(rowsq && slopes && fscale && d1 && rowsq_ld >= nslab && ldd >= H1,
+                "agx_gp_finalize: bad argument");
+  AGX_CHECK_ARG(ncov == 0 || xcov, "agx_gp_finalize: xcov missing");
+  if (B <= 0) return AGX_OK;
+  hipLaunchKernelGGL(gp_finalize_kernel, dim3(B), dim3(256), 0, agx::as_stream(stream), rowsq,
+                     rowsq_ld, nslab, slopes, fscale, d1, ldd, H1, xcov, ldx, ncov, coef);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
 extern "C" int agx_gp_rownorm_scale(void *stream, float *g, int32_t ldg, float *slopes, int32_t B,
                                     int32_t G, float coef) {
   AGX_CHECK_ARG(g && slopes && ldg >= G, "agx_gp_rownorm_scale: bad argument");
@@ -489,7 +573,7 @@ extern "C" int agx_rng_normal(void *stream, float *out, int64_t n, uint64_t seed
   if (n == 0) return AGX_OK;
   hipLaunchKernelGGL(rng_kernel<true>, dim3(grid_for((n + 3) / 4)), dim3(256), 0,
                      agx::as_stream(stream), out, (long long)n, (unsigned long long)seed,
-                     (unsigned long long)offset);
+                     (unsigned long long)offset, (const unsigned long long *)nullptr);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
@@ -500,7 +584,31 @@ extern "C" int agx_rng_uniform(void *stream, float *out, int64_t n, uint64_t see
   if (n == 0) return AGX_OK;
   hipLaunchKernelGGL(rng_kernel<false>, dim3(grid_for((n + 3) / 4)), dim3(256), 0,
                      agx::as_stream(stream), out, (long long)n, (unsigned long long)seed,
-                     (unsigned long long)offset);
+                     (unsigned long long)offset, (const unsigned long long *)nullptr);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_rng_at(void *stream, float *out, int64_t n, uint64_t seed, const uint64_t *base_dev,
+                          uint64_t sub_offset, int32_t normal) {
+  AGX_CHECK_ARG(out && base_dev && n >= 0, "agx_rng_at: bad argument");
+  if (n == 0) return AGX_OK;
+  if (normal)
+    hipLaunchKernelGGL(rng_kernel<true>, dim3(grid_for((n + 3) / 4)), dim3(256), 0,
+                       agx::as_stream(stream), out, (long long)n, (unsigned long long)seed,
+                       (unsigned long long)sub_offset, (const unsigned long long *)base_dev);
+  else
+    hipLaunchKernelGGL(rng_kernel<false>, dim3(grid_for((n + 3) / 4)), dim3(256), 0,
+                       agx::as_stream(stream), out, (long long)n, (unsigned long long)seed,
+                       (unsigned long long)sub_offset, (const unsigned long long *)base_dev);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_set_u64(void *stream, uint64_t *dst, uint64_t value) {
+  AGX_CHECK_ARG(dst, "agx_set_u64: null");
+  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, agx::as_stream(stream),
+                     (unsigned long long *)dst, (unsigned long long)value);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

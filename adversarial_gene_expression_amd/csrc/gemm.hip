@@ -22,7 +22,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
+constexpr int BK = 32;  // K granularity of split-K chunks; per-config K-tile depth is a template parameter
 
 struct KParams {
   const float *A, *B;
@@ -37,6 +37,9 @@ struct KParams {
   const float *mask;
   int ldmask;
   int accumulate;
+  const float *rowscale;  // v *= rowscale[row] (before bias)
+  float *rowsq;           // [M, rowsq_ld]: per 32-column slab sum of squares of the stored values
+  int rowsq_ld;
   float *ws;
   int splitk, kchunk;
   // SYRK only
@@ -44,8 +47,9 @@ struct KParams {
   int tiles_1d;
 };
 
-__device__ __forceinline__ void epilogue_store(const KParams &p, int row, int col, float v) {
+__device__ __forceinline__ float epilogue_store(const KParams &p, int row, int col, float v) {
   v *= p.alpha;
+  if (p.rowscale) v *= p.rowscale[row];
   if (p.bias) v += p.bias[col];
   if (p.addrow) v += p.addrow[(size_t)(row % p.addmod) * p.ldadd + col];
   if (p.act) v = v > 0.f ? v : v * p.slope;
@@ -56,10 +60,55 @@ __device__ __forceinline__ void epilogue_store(const KParams &p, int row, int co
   float *c = p.C + (size_t)row * p.ldc + col;
   if (p.accumulate) v += *c;
   *c = v;
+  return v;
+}
+
+// Same epilogue for NV values of ONE column: all side loads (bias, addrow, mask, old C) are issued
+// up front with clamped (always valid) indices, so they overlap instead of one round trip each.
+// Returns the stored values in v (0 for elements outside the matrix).
+template <int NV>
+__device__ __forceinline__ void epilogue_column(const KParams &p, const int (&rows)[NV], int col,
+                                                float (&v)[NV]) {
+  const int cc = min(col, p.N - 1);
+  const bool colok = col < p.N;
+  float bias = 0.f, add[NV], mk[NV], old[NV], rs[NV];
+  int cr[NV];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) cr[e] = min(rows[e], p.M - 1);
+  if (p.bias) bias = p.bias[cc];
+  if (p.rowscale) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) rs[e] = p.rowscale[cr[e]];
+  }
+  if (p.addrow) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) add[e] = p.addrow[(size_t)(cr[e] % p.addmod) * p.ldadd + cc];
+  }
+  if (p.mask) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) mk[e] = p.mask[(size_t)cr[e] * p.ldmask + cc];
+  }
+  if (p.accumulate) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) old[e] = p.C[(size_t)cr[e] * p.ldc + cc];
+  }
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    float x = v[e] * p.alpha;
+    if (p.rowscale) x *= rs[e];
+    if (p.bias) x += bias;
+    if (p.addrow) x += add[e];
+    if (p.act) x = x > 0.f ? x : x * p.slope;
+    if (p.mask) x = mk[e] > 0.f ? x : x * p.slope;
+    if (p.accumulate) x += old[e];
+    const bool ok = colok && rows[e] < p.M;
+    if (ok) p.C[(size_t)rows[e] * p.ldc + col] = x;
+    v[e] = ok ? x : 0.f;
+  }
 }
 
 // ---- operand tile: ROWS x BK --------------------------------------------
-template <int ROWS, bool KC, int NT, bool VEC>
+template <int ROWS, bool KC, int NT, bool VEC, int BK>
 struct Tile {
   static constexpr int F4 = ROWS * BK / 4;
   static constexpr int PT = F4 / NT;  // float4 per thread
@@ -77,6 +126,10 @@ struct Tile {
     }
   }
 
+  // Branch-free global loads: every address is clamped into the operand, so that hipcc issues
+  // all loads of a tile back to back and waits only where the values are consumed (a load under
+  // a per-element condition becomes a branch with its own s_waitcnt vmcnt(0) and serialises the
+  // whole pipeline).  Out-of-range elements are zeroed later, in store().
   __device__ static __forceinline__ void load(const float *__restrict__ src, int ld, int r0, int R,
                                               int k0, int kend, int tid, float4 (&reg)[PT]) {
 #pragma unroll
@@ -84,53 +137,64 @@ struct Tile {
       int r, k;
       coords(tid + i * NT, r, k);
       const int gr = r0 + r, gk = k0 + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < R && gk < kend) {
-        if (KC) {
-          const float *s = src + (size_t)gr * ld + gk;
-          if (VEC) {
-            v = *reinterpret_cast<const float4 *>(s);
-            if (gk + 1 >= kend) v.y = 0.f;
-            if (gk + 2 >= kend) v.z = 0.f;
-            if (gk + 3 >= kend) v.w = 0.f;
-          } else {
-            v.x = s[0];
-            if (gk + 1 < kend) v.y = s[1];
-            if (gk + 2 < kend) v.z = s[2];
-            if (gk + 3 < kend) v.w = s[3];
-          }
+      float4 v;
+      if (KC) {
+        const int cr = min(gr, R - 1);
+        if (VEC) {
+          const int ck = min(gk, (kend - 1) & ~3);
+          v = *reinterpret_cast<const float4 *>(src + (size_t)cr * ld + ck);
         } else {
-          const float *s = src + (size_t)gk * ld + gr;
-          if (VEC) {
-            v = *reinterpret_cast<const float4 *>(s);
-            if (gr + 1 >= R) v.y = 0.f;
-            if (gr + 2 >= R) v.z = 0.f;
-            if (gr + 3 >= R) v.w = 0.f;
-          } else {
-            v.x = s[0];
-            if (gr + 1 < R) v.y = s[1];
-            if (gr + 2 < R) v.z = s[2];
-            if (gr + 3 < R) v.w = s[3];
-          }
+          const float *s = src + (size_t)cr * ld;
+          const int kl = kend - 1;
+          v.x = s[min(gk, kl)];
+          v.y = s[min(gk + 1, kl)];
+          v.z = s[min(gk + 2, kl)];
+          v.w = s[min(gk + 3, kl)];
+        }
+      } else {
+        const int ck = min(gk, kend - 1);
+        if (VEC) {
+          const int cr = min(gr, (R - 1) & ~3);
+          v = *reinterpret_cast<const float4 *>(src + (size_t)ck * ld + cr);
+        } else {
+          const float *s = src + (size_t)ck * ld;
+          const int rl = R - 1;
+          v.x = s[min(gr, rl)];
+          v.y = s[min(gr + 1, rl)];
+          v.z = s[min(gr + 2, rl)];
+          v.w = s[min(gr + 3, rl)];
         }
       }
       reg[i] = v;
     }
   }
 
-  __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[PT]) {
+  __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[PT], int r0,
+                                               int R, int k0, int kend) {
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       int r, k;
       coords(tid + i * NT, r, k);
+      const int gr = r0 + r, gk = k0 + k;
+      float4 v = reg[i];
       if (KC) {
+        const bool rv = gr < R;
+        v.x = (rv && gk < kend) ? v.x : 0.f;
+        v.y = (rv && gk + 1 < kend) ? v.y : 0.f;
+        v.z = (rv && gk + 2 < kend) ? v.z : 0.f;
+        v.w = (rv && gk + 3 < kend) ? v.w : 0.f;
         float *d = lds + r * (BK + 1) + k;  // odd stride: 4 scalar stores, conflict free
-        d[0] = reg[i].x;
-        d[1] = reg[i].y;
-        d[2] = reg[i].z;
-        d[3] = reg[i].w;
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+        d[3] = v.w;
       } else {
-        *reinterpret_cast<float4 *>(lds + k * ROWS + r) = reg[i];
+        const bool kv = gk < kend;
+        v.x = (kv && gr < R) ? v.x : 0.f;
+        v.y = (kv && gr + 1 < R) ? v.y : 0.f;
+        v.z = (kv && gr + 2 < R) ? v.z : 0.f;
+        v.w = (kv && gr + 3 < R) ? v.w : 0.f;
+        *reinterpret_cast<float4 *>(lds + k * ROWS + r) = v;
       }
     }
   }
@@ -154,13 +218,13 @@ __device__ __forceinline__ void tri_decode(long long t, int T, int &ti, int &tj)
   tj = i + (int)(t - start(i));
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32>
 __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert(TM >= 1 && TN >= 1, "wave tile");
-  using TileA = Tile<BM, !TA, NT, VEC>;
-  using TileB = Tile<BN, TB, NT, VEC>;
+  using TileA = Tile<BM, !TA, NT, VEC, BK>;
+  using TileB = Tile<BN, TB, NT, VEC, BK>;
   constexpr int STAGE = TileA::LDS_FLOATS + TileB::LDS_FLOATS;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -195,8 +259,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   if (nt > 0) {
     TileA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
     TileB::load(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
-    TileA::store(smem, tid, ra);
-    TileB::store(smem + TileA::LDS_FLOATS, tid, rb);
+    TileA::store(smem, tid, ra, m0, p.M, kbeg, kend);
+    TileB::store(smem + TileA::LDS_FLOATS, tid, rb, n0, p.N, kbeg, kend);
   }
   __syncthreads();
 
@@ -225,8 +289,9 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
     }
     if (more) {
       float *nA = smem + ((t + 1) & 1) * STAGE;
-      TileA::store(nA, tid, ra);
-      TileB::store(nA + TileA::LDS_FLOATS, tid, rb);
+      const int k0 = kbeg + (t + 1) * BK;
+      TileA::store(nA, tid, ra, m0, p.M, k0, kend);
+      TileB::store(nA + TileA::LDS_FLOATS, tid, rb, n0, p.N, k0, kend);
     }
     __syncthreads();
   }
@@ -262,14 +327,28 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
           }
         }
       } else {
+        int rows[16];
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < p.M && col < p.N) {
-            if (p.splitk > 1)
-              p.ws[((size_t)z * p.M + row) * p.N + col] = acc[i][j][r];
-            else
-              epilogue_store(p, row, col, acc[i][j][r]);
+          rows[r] = rbase + (r & 3) + 8 * (r >> 2);
+          v[r] = acc[i][j][r];
+        }
+        if (p.splitk > 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (rows[r] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[r]) * p.N + col] = v[r];
+        } else {
+          epilogue_column<16>(p, rows, col, v);
+          if (p.rowsq) {  // deterministic per-slab partial of sum_col v^2 (only without split-K)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float q = v[r] * v[r];
+#pragma unroll
+              for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+              if (l31 == 0 && rows[r] < p.M && col < p.N)
+                p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
+            }
           }
         }
       }
@@ -277,46 +356,209 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   }
 }
 
+// Split-K reduction + epilogue.  blockDim = (64 lanes over 4-element chunks, 4 split phases):
+// each thread sums every 4th slab for its 4 consecutive outputs, the 4 phases meet in LDS.
+template <bool VEC4>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const KParams p) {
+  __shared__ float4 red[3][64];
   const size_t mn = (size_t)p.M * p.N;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < mn;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int s = 0; s < p.splitk; ++s) v += p.ws[(size_t)s * mn + idx];
-    epilogue_store(p, (int)(idx / p.N), (int)(idx % p.N), v);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const size_t idx = ((size_t)blockIdx.x * 64 + tx) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < mn) {
+    for (int s = ty; s < p.splitk; s += 4) {
+      const float *src = p.ws + (size_t)s * mn + idx;
+      if (VEC4) {
+        const float4 v = *reinterpret_cast<const float4 *>(src);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      } else {
+        a.x += src[0];
+        if (idx + 1 < mn) a.y += src[1];
+        if (idx + 2 < mn) a.z += src[2];
+        if (idx + 3 < mn) a.w += src[3];
+      }
+    }
+  }
+  if (ty > 0) red[ty - 1][tx] = a;
+  __syncthreads();
+  if (ty == 0 && idx < mn) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 v = red[k][tx];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const float vals[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (idx + e < mn) epilogue_store(p, (int)((idx + e) / p.N), (int)((idx + e) % p.N), vals[e]);
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK>
-int launch(hipStream_t st, const KParams &p, int tiles) {
-  using TileA = Tile<BM, !TA, WM * WN * 64, VEC>;
-  using TileB = Tile<BN, TB, WM * WN * 64, VEC>;
-  constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
-  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK>;
-  static thread_local int attr_device = -2;
-  int dev = -1;
-  AGX_HIP(hipGetDevice(&dev));
-  if (attr_device != dev) {
-    AGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_device = dev;
+
+// ---------------------------------------------------------------------------
+// Latency-oriented kernel for skinny / small products (batch 32 regime and the hidden layers):
+// one 32x32 output tile per 4-wave block, the block's K range is split over the 4 waves in
+// interleaved groups of 8, every lane loads its MFMA fragments STRAIGHT from global memory
+// (k-contiguous operand: one 16-B load = 4 consecutive k of the lane's row; row-contiguous
+// operand: 4 coalesced dword loads), U groups are issued before the first MFMA, so a wave pays
+// one memory round trip per 8*U k instead of one per staged K-tile.  The k order inside a
+// group is permuted identically for A and B (lane half h takes k = 4h..4h+3), which leaves the
+// product unchanged.  The 4 partial tiles meet in LDS; split-K over blocks uses the same
+// partial-slab + reduce path as the tiled kernel.
+// ---------------------------------------------------------------------------
+// branch-free: addresses clamped into the operand, masking by select after the load
+template <bool KC, bool VEC>
+__device__ __forceinline__ void frag_load4(const float *__restrict__ src, int ld, int r, int R, int k,
+                                           int kend, float (&v)[4]) {
+  const int kl = kend - 1;
+  const int cr = min(r, R - 1);
+  if (KC) {
+    const float *s = src + (size_t)cr * ld;
+    if (VEC) {
+      const float4 q = *reinterpret_cast<const float4 *>(s + min(k, kl & ~3));
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      v[0] = s[min(k, kl)]; v[1] = s[min(k + 1, kl)]; v[2] = s[min(k + 2, kl)]; v[3] = s[min(k + 3, kl)];
+    }
+  } else {
+    const float *s = src + cr;
+    v[0] = s[(size_t)min(k, kl) * ld];
+    v[1] = s[(size_t)min(k + 1, kl) * ld];
+    v[2] = s[(size_t)min(k + 2, kl) * ld];
+    v[3] = s[(size_t)min(k + 3, kl) * ld];
   }
+  const bool rv = r < R;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (rv && k + e < kend) ? v[e] : 0.f;
+}
+
+template <bool TA, bool TB, bool VEC, int U>
+__global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int tiles_n = (p.N + 31) / 32;
+  const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  const int z = blockIdx.y;
+  const int kbeg = z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int ngroups = (kend - kbeg + 7) / 8;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // pass p covers groups [4U*p, 4U*(p+1)); wave w takes U consecutive ones, so that a wave's
+  // loads of a k-contiguous row walk whole cache lines
+  for (int g0 = wave * U; g0 < ngroups; g0 += 4 * U) {
+    float av[U][4], bv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = kbeg + 8 * (g0 + u) + 4 * h;
+      frag_load4<!TA, VEC>(p.A, p.lda, m0 + i, p.M, k, kend, av[u]);
+      frag_load4<TB, VEC>(p.B, p.ldb, n0 + i, p.N, k, kend, bv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
+  __syncthreads();
+  {
+    const int cc = tid & 31, col = n0 + cc;
+    int rows[4];
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = (tid >> 5) + 8 * q;
+      rows[q] = m0 + rr;
+      v[q] = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc];
+    }
+    if (p.splitk > 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (rows[q] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[q]) * p.N + col] = v[q];
+    } else {
+      epilogue_column<4>(p, rows, col, v);
+      if (p.rowsq) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float sq = v[q] * v[q];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+          if (cc == 0 && rows[q] < p.M && col < p.N) p.rowsq[(size_t)rows[q] * p.rowsq_ld + (col >> 5)] = sq;
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int groups_per_wave) {
+  dim3 grid(tiles, p.splitk, 1), block(256, 1, 1);
+#define AGX_DIRECT(V, UU) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, V, UU>), grid, block, 0, st, p)
+#define AGX_DIRECT_U(V)                         \
+  do {                                          \
+    if (groups_per_wave <= 1) AGX_DIRECT(V, 1); \
+    else if (groups_per_wave <= 2) AGX_DIRECT(V, 2); \
+    else if (groups_per_wave <= 4) AGX_DIRECT(V, 4); \
+    else if (groups_per_wave <= 6 || (groups_per_wave > 8 && groups_per_wave <= 12)) AGX_DIRECT(V, 6); \
+    else AGX_DIRECT(V, 8);                      \
+  } while (0)
+  if (vec) AGX_DIRECT_U(true); else AGX_DIRECT_U(false);
+#undef AGX_DIRECT_U
+#undef AGX_DIRECT
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32>
+int launch(hipStream_t st, const KParams &p, int tiles) {
+  using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
+  using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
+  constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
+  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK>;  // LDS limit raised in agx_init
   dim3 grid(tiles, p.splitk, 1), block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32>
+int prepare_one() {
+  using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
+  using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
+  constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
+  AGX_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void *>(gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return AGX_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int BK = 32>
+int prepare_cfg() {
+  AGX_TRY((prepare_one<BM, BN, WM, WN, false, false, true, false, BK>()));
+  AGX_TRY((prepare_one<BM, BN, WM, WN, false, false, false, false, BK>()));
+  AGX_TRY((prepare_one<BM, BN, WM, WN, false, true, true, false, BK>()));
+  AGX_TRY((prepare_one<BM, BN, WM, WN, false, true, false, false, BK>()));
+  AGX_TRY((prepare_one<BM, BN, WM, WN, true, false, true, false, BK>()));
+  AGX_TRY((prepare_one<BM, BN, WM, WN, true, false, false, false, BK>()));
+  return AGX_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch_layout(hipStream_t st, const KParams &p, int tiles, int ta, int tb, bool vec) {
   if (!ta && !tb)
-    return vec ? launch<BM, BN, WM, WN, false, false, true, false>(st, p, tiles)
-               : launch<BM, BN, WM, WN, false, false, false, false>(st, p, tiles);
+    return vec ? launch<BM, BN, WM, WN, false, false, true, false, BK>(st, p, tiles)
+               : launch<BM, BN, WM, WN, false, false, false, false, BK>(st, p, tiles);
   if (!ta && tb)
-    return vec ? launch<BM, BN, WM, WN, false, true, true, false>(st, p, tiles)
-               : launch<BM, BN, WM, WN, false, true, false, false>(st, p, tiles);
-  return vec ? launch<BM, BN, WM, WN, true, false, true, false>(st, p, tiles)
-             : launch<BM, BN, WM, WN, true, false, false, false>(st, p, tiles);
+    return vec ? launch<BM, BN, WM, WN, false, true, true, false, BK>(st, p, tiles)
+               : launch<BM, BN, WM, WN, false, true, false, false, BK>(st, p, tiles);
+  return vec ? launch<BM, BN, WM, WN, true, false, true, false, BK>(st, p, tiles)
+             : launch<BM, BN, WM, WN, true, false, false, false, BK>(st, p, tiles);
 }
 
 struct Plan {
@@ -326,30 +568,41 @@ struct Plan {
 Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_floats) {
   Plan pl;
   const int cus = agx::num_cus();
+  const int ktiles = agx::cdiv(K, BK);
   int cfg = force_cfg;
   if (cfg < 0) {
     const long long tilesL = (long long)agx::cdiv(M, 128) * agx::cdiv(N, 128);
-    if (M <= 32)
-      cfg = 2;
+    if (M <= 128 || ((long long)M * N <= (1 << 19) && K <= 2048))
+      cfg = 3;  // skinny or small: latency-oriented direct kernel
     else if (tilesL >= cus || (M > 64 && N > 64 && (long long)K * tilesL >= 40000))
       cfg = 0;
     else
       cfg = 1;
   }
   pl.cfg = cfg;
-  pl.bm = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32);
-  pl.bn = cfg == 0 ? 128 : (cfg == 1 ? 64 : 128);
+  pl.bm = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : 32);
+  pl.bn = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : (cfg == 2 ? 128 : 32));
   pl.tiles = agx::cdiv(M, pl.bm) * agx::cdiv(N, pl.bn);
-  const int ktiles = agx::cdiv(K, BK);
   int sk = force_splitk;
   if (sk <= 0) {
     sk = 1;
-    if (pl.tiles < (cus * 3) / 4 && ktiles >= 8) {
-      sk = agx::cdiv(2 * cus, pl.tiles);
-      if (sk > ktiles / 4) sk = ktiles / 4;  // keep >= 4 K-tiles per slice
-      if (sk > 128) sk = 128;
-      if (sk < 1) sk = 1;
+    if (cfg == 3) {
+      // keep the per-block K range around 128..512 (1-2 load rounds per wave) while the grid
+      // stays within a few waves of workgroups
+      if (K > 512) {
+        sk = std::min(agx::cdiv(K, 128), agx::cdiv(4 * cus, pl.tiles));
+        if (sk > agx::cdiv(K, 128)) sk = agx::cdiv(K, 128);
+      }
+    } else {
+      // workgroups that can be resident at once (LDS-limited): one round of blocks, no tail round
+      const int slots = cus * ((cfg == 0 || cfg == 5) ? 2 : 4);
+      if (pl.tiles * 2 <= slots && ktiles >= 32) {
+        sk = slots / pl.tiles;                 // fill the resident slots exactly once
+        if (sk > ktiles / 4) sk = ktiles / 4;  // keep >= 4 K-tiles per slice
+      }
     }
+    if (sk > 128) sk = 128;
+    if (sk < 1) sk = 1;
   }
   if (sk > ktiles) sk = ktiles > 0 ? ktiles : 1;
   const int64_t mn = (int64_t)M * N;
@@ -363,6 +616,22 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
 }
 
 }  // namespace
+
+namespace agx {
+// Raise the dynamic-LDS limit of every GEMM instantiation on the current device (called from
+// agx_init, so that no attribute call happens inside a stream capture).
+int gemm_prepare_device() {
+  AGX_TRY((prepare_cfg<128, 128, 2, 2>()));
+  AGX_TRY((prepare_cfg<64, 64, 2, 2>()));
+  AGX_TRY((prepare_cfg<32, 128, 1, 4>()));
+  AGX_TRY((prepare_cfg<128, 128, 2, 4>()));
+  AGX_TRY((prepare_cfg<128, 128, 2, 2, 16>()));
+  AGX_TRY((prepare_cfg<128, 128, 2, 4, 16>()));
+  AGX_TRY((prepare_one<128, 128, 2, 2, true, false, true, true>()));
+  AGX_TRY((prepare_one<128, 128, 2, 2, true, false, false, true>()));
+  return AGX_OK;
+}
+}  // namespace agx
 
 extern "C" int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K) {
   Plan pl = make_plan(M, N, K, -1, -1, INT64_MAX);
@@ -380,7 +649,7 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
   AGX_CHECK_ARG(g->ldc >= g->N, "agx_gemm_f32: ldc %d < N %d", g->ldc, g->N);
   AGX_CHECK_ARG(!g->addrow || (g->addmod > 0 && g->ldadd >= g->N), "agx_gemm_f32: bad addrow");
   AGX_CHECK_ARG(!g->mask || g->ldmask >= g->N, "agx_gemm_f32: bad mask ld");
-  AGX_CHECK_ARG(g->force_cfg <= 2, "agx_gemm_f32: force_cfg out of range");
+  AGX_CHECK_ARG(g->force_cfg <= 7, "agx_gemm_f32: force_cfg out of range");
 
   KParams p{};
   p.A = g->A; p.B = g->B; p.C = g->C;
@@ -390,8 +659,14 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
   p.bias = g->bias; p.addrow = g->addrow; p.addmod = g->addmod; p.ldadd = g->ldadd;
   p.act = g->act; p.slope = g->slope; p.mask = g->mask; p.ldmask = g->ldmask;
   p.accumulate = g->accumulate;
+  p.rowscale = g->rowscale;
+  p.rowsq = g->rowsq;
+  p.rowsq_ld = g->rowsq_ld;
   p.ws = g->ws;
-  Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->force_splitk, g->ws ? g->ws_floats : 0);
+  AGX_CHECK_ARG(!g->rowsq || g->rowsq_ld >= agx::cdiv(g->N, 32), "agx_gemm_f32: rowsq_ld too small");
+  // the row sum-of-squares side output is produced by the main kernel: no split-K with it
+  Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk,
+                      g->ws ? g->ws_floats : 0);
   p.splitk = pl.splitk;
   p.kchunk = pl.kchunk;
   const bool vec = agx::aligned16(g->A) && agx::aligned16(g->B) && (g->lda % 4 == 0) && (g->ldb % 4 == 0);
@@ -404,13 +679,28 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
     rc = launch_layout<128, 128, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 1)
     rc = launch_layout<64, 64, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
-  else
+  else if (pl.cfg == 2)
     rc = launch_layout<32, 128, 1, 4>(st, p, pl.tiles, g->ta, g->tb, vec);
+  else if (pl.cfg == 5)
+    rc = launch_layout<128, 128, 2, 4>(st, p, pl.tiles, g->ta, g->tb, vec);
+  else if (pl.cfg == 6)
+    rc = launch_layout<128, 128, 2, 2, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
+  else if (pl.cfg == 7)
+    rc = launch_layout<128, 128, 2, 4, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
+  else {
+    const int gpw = agx::cdiv(agx::cdiv(std::min(p.kchunk, p.K), 8), 4);  // 8-wide k groups per wave
+    if (!g->ta && !g->tb) rc = launch_direct<false, false>(st, p, pl.tiles, vec, gpw);
+    else if (!g->ta && g->tb) rc = launch_direct<false, true>(st, p, pl.tiles, vec, gpw);
+    else rc = launch_direct<true, false>(st, p, pl.tiles, vec, gpw);
+  }
   if (rc != AGX_OK) return rc;
   if (p.splitk > 1) {
     const int64_t mn = (int64_t)p.M * p.N;
-    int blocks = (int)std::min<int64_t>(agx::cdiv64(mn, 256), 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    const int blocks = (int)agx::cdiv64(mn, 256);
+    if (mn % 4 == 0 && agx::aligned16(p.ws))
+      hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, p);
     AGX_LAUNCH_CHECK();
   }
   return AGX_OK;

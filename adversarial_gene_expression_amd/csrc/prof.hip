@@ -60,11 +60,61 @@ ProfScope::~ProfScope() {
 
 }  // namespace agx
 
+namespace {
+// Bounded busy-wait (100 MHz wall clock); lets the host queue a whole iteration behind it so that
+// the event brackets that follow time back-to-back GPU execution, not host launch gaps.
+__global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 24); ++i) {
+    if (wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+}  // namespace
+
+namespace {
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+// measures the shader clock a short MFMA-dense kernel actually gets: s_memtime ticks per
+// 100 MHz wall-clock tick over `n` dependent 32x32x2 MFMAs per wave
+__global__ void __launch_bounds__(256) clock_probe_kernel(int n, float seed, float *out) {
+  f32x16p acc;
+  for (int r = 0; r < 16; ++r) acc[r] = seed;
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  float a = seed + threadIdx.x, b = seed - 1.f;
+  for (int i = 0; i < n; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  float sum = 0.f;
+  for (int r = 0; r < 16; ++r) sum += acc[r];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = (float)((double)(c1 - c0) / (double)(w1 - w0) * 100.0);  // MHz
+    out[1] = (float)(c1 - c0) / (float)n;                              // cycles per MFMA
+    out[2] = sum;
+  }
+}
+}  // namespace
+
+extern "C" int agx_prof_clock(void *stream, int32_t blocks, int32_t mfmas, float *out_dev) {
+  AGX_CHECK_ARG(out_dev && blocks > 0 && blocks <= 4096 && mfmas > 0 && mfmas <= (1 << 20), "agx_prof_clock: bad argument");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, agx::as_stream(stream), mfmas, 0.f, out_dev);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_prof_spin(void *stream, int32_t microseconds) {
+  AGX_CHECK_ARG(microseconds >= 0 && microseconds <= 100000, "agx_prof_spin: 0..100000 us");
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, agx::as_stream(stream),
+                     (unsigned long long)microseconds * 100ull);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
 extern "C" int agx_prof_enable(int32_t filter) {
   AGX_CHECK_ARG(filter >= -2 && filter < AGX_K_COUNT, "agx_prof_enable: bad filter %d", filter);
   g_filter = filter;
   return AGX_OK;
 }
+
+extern "C" int agx_prof_enabled(void) { return g_filter != -2; }
 
 extern "C" int agx_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -35,5 +35,6 @@ extern "C" int agx_init(int device) {
     return AGX_E_INVALID;
   }
   g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  AGX_TRY(agx::gemm_prepare_device());
   return AGX_OK;
 }

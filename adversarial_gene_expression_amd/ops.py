@@ -11,7 +11,7 @@ from ._dev import ptr
 
 
 def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0, slope=0.0, mask=None,
-         out=None, accumulate=False, force_cfg=-1, force_splitk=0, use_ws=True):
+         out=None, accumulate=False, rowscale=None, rowsq=None, force_cfg=-1, force_splitk=0, use_ws=True):
     """out[M, N] = epilogue(alpha * op(A) @ op(B)); leading dimensions are the row strides."""
     lib = _lib.load()
     if out is None:
@@ -29,6 +29,9 @@ def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0,
     if mask is not None:
         g.mask, g.ldmask = ptr(mask), mask.stride(0)
     g.accumulate = int(accumulate)
+    g.rowscale = ptr(rowscale)
+    if rowsq is not None:
+        g.rowsq, g.rowsq_ld = ptr(rowsq), rowsq.stride(0)
     ws = None
     if use_ws:
         wsf = max(int(lib.agx_gemm_ws_floats(M, N, K)), (force_splitk if force_splitk > 0 else 0) * M * N)

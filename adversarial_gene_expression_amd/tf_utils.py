@@ -405,11 +405,15 @@ class RMSprop:
         self._state = {}
         self.iterations = 0
 
-    def apply(self, net, grad_scale=1.0):
-        lib = _lib.load()
+    def slot(self, net):
         rms = self._state.get(id(net))
         if rms is None:
             rms = self._state[id(net)] = _dev.zeros(net.n_flat)
+        return rms
+
+    def apply(self, net, grad_scale=1.0):
+        lib = _lib.load()
+        rms = self.slot(net)
         _lib.check(lib.agx_opt_rmsprop(_dev.stream(), ptr(net.params), ptr(net.grads), ptr(rms), net.n_flat,
                                        self.learning_rate, self.rho, self.epsilon, grad_scale), 'agx_opt_rmsprop')
         self.iterations += 1
@@ -475,10 +479,54 @@ class _Pair:
         _lib.check(lib.agx_cgan_bind(self.handle, ptr(gen.params), ptr(gen.grads), ptr(disc.params), ptr(disc.grads),
                                      ptr(self.workspace), self.workspace.numel() * 4), 'agx_cgan_bind')
 
+        self._graphs = {}
+        self._keep = {}
+
+    def iteration_graph(self, gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, aug_d=None, aug_g=None):
+        """Capture (once per key) the whole loop iteration of tf_utils.py:316-323 as a hipGraph."""
+        key = (B, nb_critic, float(gp_weight), int(seed), id(gen_opt), id(disc_opt), gen_opt.learning_rate,
+               disc_opt.learning_rate, id(aug_d), id(aug_g))
+        g = self._graphs.get(key)
+        if g is None:
+            lib = _lib.load()
+            a = _lib.IterArgs()
+            a.B, a.nb_critic, a.gp_weight = B, nb_critic, gp_weight
+            a.lr_disc, a.lr_gen = disc_opt.learning_rate, gen_opt.learning_rate
+            a.rho, a.eps = disc_opt.rho, disc_opt.epsilon
+            a.disc_rms, a.gen_rms = ptr(disc_opt.slot(disc)), ptr(gen_opt.slot(gen))
+            a.seed = int(seed)
+            if aug_d is not None:
+                a.aug_mask_disc, a.aug_noise_fake, a.aug_noise_real = (ptr(aug_d['mask']), ptr(aug_d['noise_fake']),
+                                                                       ptr(aug_d['noise_real']))
+            if aug_g is not None:
+                a.aug_mask_gen, a.aug_noise_gen = ptr(aug_g['mask']), ptr(aug_g['noise'])
+            self._keep[key] = (aug_d, aug_g)
+            g = _lib.C.c_void_p()
+            side = torch.cuda.Stream()          # capture needs a non-default stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _lib.check(lib.agx_cgan_iter_capture(self.handle, _dev.stream(), a, _lib.C.byref(g)),
+                           'agx_cgan_iter_capture')
+            torch.cuda.current_stream().wait_stream(side)
+            self._graphs[key] = g
+        return g
+
+    def drop_graphs(self):
+        """Forget captured iterations (e.g. after toggling agx_prof_enable, whose event brackets
+        are baked into a graph at capture time)."""
+        torch.cuda.synchronize()
+        lib = _lib.load()
+        for g in self._graphs.values():
+            lib.agx_cgan_iter_destroy(g)
+        self._graphs.clear()
+
     def __del__(self):
         try:
+            lib = _lib.load()
+            for g in self._graphs.values():
+                lib.agx_cgan_iter_destroy(g)
             if self.handle:
-                _lib.load().agx_cgan_destroy(self.handle)
+                lib.agx_cgan_destroy(self.handle)
         except Exception:
             pass
 
@@ -602,6 +650,41 @@ def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None,
     return DeviceArray(gen.grads[gen.n_flat:gen.n_flat + 1].clone())
 
 
+def _graph_ok(gen_opt, disc_opt, world):
+    return (world == 1 and type(gen_opt) is RMSprop and type(disc_opt) is RMSprop
+            and gen_opt.rho == disc_opt.rho and gen_opt.epsilon == disc_opt.epsilon)
+
+
+def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_penalty_weight=10, p_aug=0,
+                    norm_scale=0.5):
+    """One iteration of the reference loop body (tf_utils.py:314-324) - ``nb_critic`` critic steps
+    with fresh z / alpha on the same real batch, then one generator step - replayed as ONE hipGraph.
+    Draws come from the module Philox stream at the same positions the eager ``train_disc`` /
+    ``train_gen`` calls would use.  Returns (last critic loss, generator loss) as DeviceArrays.
+    Single GPU, RMSprop on both nets (the reference defaults); ``train`` falls back to the eager
+    step functions otherwise."""
+    lib = _lib.load()
+    x = _dev.to_dev(x)
+    cc = _dev.to_dev(cc, torch.int32)
+    nc = _dev.to_dev(nc)
+    B = x.shape[0]
+    if not _graph_ok(gen_opt, disc_opt, _world()[0]):
+        raise ValueError('train_iteration needs one GPU and RMSprop on both networks')
+    pair = _pair(gen, disc, B)
+    aug_d = aug_g = None
+    if p_aug:   # same per-trace constants, drawn in the order the reference's first calls would (:202-210, :240-247)
+        aug_d = _aug_constants('disc', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
+        aug_g = _aug_constants('gen', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
+    g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, grad_penalty_weight, _rng.seed, aug_d, aug_g)
+    losses = _dev.empty((nb_critic + 1, 4))
+    _lib.check(lib.agx_cgan_iter_launch(g, _dev.stream(), ptr(x), x.stride(0), ptr(cc), ptr(nc), _rng.offset,
+                                        ptr(losses)), 'agx_cgan_iter_launch')
+    _rng.offset += int(lib.agx_cgan_iter_rng_draws(g))
+    disc_opt.iterations += nb_critic
+    gen_opt.iterations += 1
+    return (DeviceArray(losses[nb_critic - 1, 2:3]) if nb_critic > 0 else None), DeviceArray(losses[nb_critic, 0:1])
+
+
 def _shard(lo, hi, world, rank):
     """Rows [lo, hi) of the global batch owned by `rank` (sizes differ by at most 1)."""
     n = hi - lo
@@ -612,12 +695,14 @@ def _shard(lo, hi, world, rank):
 
 def train(dataset, cat_covs, num_covs, z_dim, epochs, batch_size, gen, disc, score_fn, save_fn,
           gen_opt=None, disc_opt=None, nb_critic=5, verbose=True, checkpoint_dir='./checkpoints/cpkt',
-          log_dir='./logs/', patience=10, p_aug=0, norm_scale=0.5, *, noise_fn=None):
+          log_dir='./logs/', patience=10, p_aug=0, norm_scale=0.5, *, noise_fn=None, use_graph=True):
     """Train model (reference ``tf_utils.py:261-356``): sequential un-shuffled mini-batches
     including the ragged tail, ``nb_critic`` critic steps (fresh z, same real batch) then one
     generator step, evaluation / ``save_fn`` / patience every 5 epochs.
 
     The training matrix is uploaded to HBM once and batches are device slices.
+    use_graph: replay each iteration as one hipGraph (single GPU + RMSprop; bit-identical to the
+    eager step functions for equal seeds).
     noise_fn(kind, shape): optional injection of the TF draws (kind in {'z', 'alpha'}) for the
     GLOBAL batch; default is the device Philox stream.  Returns a trace dict (additive)."""
     if gen_opt is None:
@@ -649,6 +734,11 @@ def train(dataset, cat_covs, num_covs, z_dim, epochs, batch_size, gen, disc, sco
             if hi_r <= lo_r:
                 raise ValueError('global batch of %d rows cannot be split over %d ranks' % (bg, world))
             x, cc, nc = data[lo_r:hi_r], ccs[lo_r:hi_r], ncs[lo_r:hi_r]
+            if use_graph and noise_fn is None and nb_critic > 0 and _graph_ok(gen_opt, disc_opt, world):
+                d_l, g_l = train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, 10, p_aug, norm_scale)
+                dl.append(d_l)
+                gl.append(g_l)
+                continue
             disc_loss = None
             for _ in range(nb_critic):   # tf_utils.py:316-318
                 z = draw('z', bg, z_dim, lo_r - i, hi_r - i)

@@ -59,6 +59,15 @@ int agx_prof_enable(int32_t filter);
 int agx_prof_reset(void);
 int agx_prof_read(int32_t id, double *total_ms, int64_t *count, double *flops, double *bytes);
 const char *agx_prof_name(int32_t id);
+/* Queue a bounded busy-wait (<= 100 ms) so that the host can enqueue work behind it: brackets
+ * recorded after it time back-to-back GPU execution instead of host launch gaps.  Brackets are
+ * NOT usable inside a captured graph (ROCm 7.2 rejects hipEventElapsedTime on graph-recorded
+ * events): agx_cgan_iter_capture refuses to capture while profiling is enabled.            */
+int agx_prof_spin(void *stream, int32_t microseconds);
+int agx_prof_enabled(void);
+/* Clock probe: out_dev[0] = shader MHz seen by a kernel of `blocks` x 4 waves issuing `mfmas`
+ * dependent 32x32x2 fp32 MFMAs each, out_dev[1] = cycles per MFMA (measurement only). */
+int agx_prof_clock(void *stream, int32_t blocks, int32_t mfmas, float *out_dev);
 
 /* ---- dense layers: tf_utils.py:85-88, 132-135 (Dense+ReLU) and their
  *      autodiff (MatMul grads / BiasAddGrad / ReluGrad, tf_utils.py:220,255) -- */
@@ -79,9 +88,13 @@ typedef struct agx_gemm {
   const float *mask;    /* [M,N] ld=ldmask or NULL: v *= (mask>0 ? 1 : slope);   */
   int32_t ldmask;       /*   may alias C (in-place ReLU-grad)                    */
   int32_t accumulate;   /* 1: C += result                                        */
+  const float *rowscale;/* [M] or NULL: v *= rowscale[m] (applied before bias)   */
+  float *rowsq;         /* [M, rowsq_ld] or NULL: rowsq[m][n/32] = sum over the   */
+  int32_t rowsq_ld;     /*   32-column slab of C[m,:]^2 (deterministic partials;  */
+                        /*   disables split-K); rowsq_ld >= ceil(N/32)            */
   float *ws;            /* split-K scratch (floats) or NULL                      */
   int64_t ws_floats;
-  int32_t force_cfg;    /* -1 auto; 0 = 128x128, 1 = 64x64, 2 = 32x128 tiles     */
+  int32_t force_cfg;    /* -1 auto; 0/1/2 = 128x128 / 64x64 / 32x128 LDS tiles, 3 = direct 32x32 */
   int32_t force_splitk; /* <=0 auto                                              */
   int32_t prof_id;      /* AGX_K_* class for agx_prof_*; 0 with untagged = AGX_K_GEMM_UNTAGGED when prof_tagged == 0 */
   int32_t prof_tagged;  /* 1 if prof_id is meaningful                            */
@@ -128,6 +141,17 @@ int agx_rowdot(void *stream, const float *A, int32_t lda, const float *w, const 
 int agx_delta_init(void *stream, const float *A, int32_t lda, const float *w, float *delta,
                    int32_t ldd, int32_t R, int32_t H, int32_t n0, int32_t n1,
                    float c0, float c1, float c2, float slope);
+/* agx_rowdot + agx_delta_init in one launch (one wave per row). */
+int agx_critic_head(void *stream, const float *A, int32_t lda, const float *w, const float *b,
+                    float *out, float *delta, int32_t ldd, int32_t R, int32_t H, int32_t n0,
+                    int32_t n1, float c0, float c1, float c2, float slope);
+/* Gradient-penalty finalisation from the per-slab row sums of squares a GEMM left in `rowsq`
+ * (agx_gemm_t.rowsq): slopes[b] = sqrt(sum) (no epsilon, tf_utils.py:169), fscale[b] =
+ * coef*(s-1)/s, d1[b,:] *= fscale[b] (so that dW_1 = X^T.D_1 carries the penalty term with the
+ * UNSCALED input gradient left in X), xcov[b, 0:ncov] = 0.  Fixed summation order.          */
+int agx_gp_finalize(void *stream, const float *rowsq, int32_t rowsq_ld, int32_t nslab,
+                    float *slopes, float *fscale, float *d1, int32_t ldd, int32_t H1, float *xcov,
+                    int32_t ldx, int32_t ncov, int32_t B, float coef);
 /* GP slopes: s[b] = sqrt(sum_g g[b,g]^2) (NO epsilon, tf_utils.py:169);
  * then g[b,:] *= coef * (s-1)/s  (d gp / d g with coef = weight*2/B_global).   */
 int agx_gp_rownorm_scale(void *stream, float *g, int32_t ldg, float *slopes, int32_t B,
@@ -159,6 +183,11 @@ int agx_opt_adam(void *stream, float *w, const float *g, float *m, float *v, int
  * advance `offset` by the (4-rounded) number of values drawn. */
 int agx_rng_normal(void *stream, float *out, int64_t n, uint64_t seed, uint64_t offset);
 int agx_rng_uniform(void *stream, float *out, int64_t n, uint64_t seed, uint64_t offset);
+/* Same streams with the position read from device memory: offset = *base_dev + sub_offset
+ * (lets a captured graph advance its own RNG position between replays). */
+int agx_rng_at(void *stream, float *out, int64_t n, uint64_t seed, const uint64_t *base_dev,
+               uint64_t sub_offset, int32_t normal);
+int agx_set_u64(void *stream, uint64_t *dst, uint64_t value);
 
 /* ---- correlation path: utils.py:260-268, 808-873 ------------------------ */
 /* per-column mean and population std (ddof=0) of x[N,G]; sums in fp64.
@@ -243,6 +272,35 @@ typedef struct agx_step_args {
 int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a);
 /* Gradients of one generator step into gen_grads (tf_utils.py:242-255). */
 int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a);
+
+/* ---- whole loop iteration as ONE hipGraph: tf_utils.py:316-323 --------------
+ * nb_critic x (z ~ N(0,1), alpha ~ U[0,1), critic gradients, RMSprop) + (z, generator
+ * gradients, RMSprop), captured once per batch size and replayed; removes the per-kernel
+ * launch cost that dominates at batch 32 (the reference pays 6 tf.function calls + 6 eager RNG
+ * calls per 32 samples).  The draws are the SAME Philox stream positions the eager entry
+ * points would use (z then alpha per critic step, 4-aligned), so graph and eager runs with
+ * equal seeds give bit-identical weights.  Single GPU only (no collective inside).        */
+typedef struct agx_iter_args {
+  int32_t B;                /* rows of this batch (<= max_batch)                         */
+  int32_t nb_critic;        /* 5 (tf_utils.py:262)                                       */
+  float gp_weight;          /* 10                                                        */
+  float lr_disc, lr_gen, rho, eps; /* Keras RMSprop(5e-4, 0.9, 1e-7) for both nets       */
+  float *disc_rms, *gen_rms;       /* optimizer slots (flat, same layout as the params)  */
+  uint64_t seed;            /* Philox seed                                               */
+  const float *aug_mask_disc, *aug_noise_fake, *aug_noise_real; /* NULL or trace constants */
+  const float *aug_mask_gen, *aug_noise_gen;
+} agx_iter_args_t;
+typedef struct agx_iter_graph agx_iter_graph_t;
+int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter_args_t *a,
+                          agx_iter_graph_t **out);
+/* Stage the batch (device pointers, B rows) and replay.  rng_offset = stream position of the
+ * first draw; the iteration consumes agx_cgan_iter_rng_draws() positions.
+ * losses_out (device, [nb_critic+1][4]) receives [wgan, gp, total, 0] per step.            */
+int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
+                         const int32_t *cat, const float *num, uint64_t rng_offset,
+                         float *losses_out);
+int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g);
+int agx_cgan_iter_destroy(agx_iter_graph_t *g);
 
 #ifdef __cplusplus
 }

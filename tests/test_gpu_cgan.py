@@ -230,3 +230,27 @@ def test_ragged_and_max_batch_growth(gpu):
                                             O.to_torch(p32['gp']), O.to_torch(p32['dp']), t64(p32['alpha'][s]))
         assert abs(float(loss) - float(wl)) <= 1e-5 * max(1.0, abs(float(wl)))
         _check_grads(disc.get_gradients(), [g.numpy() for g in want])
+
+
+@pytest.mark.parametrize('p_aug', [0, 0.25])
+def test_graph_iteration_is_bit_identical_to_eager(gpu, p_aug):
+    """train(use_graph=True) replays one hipGraph per iteration; with equal Philox seeds it must give
+    exactly the weights, optimizer slots and losses of the eager step functions (ragged tail incl.)."""
+    from adversarial_gene_expression_amd import tf_utils as T
+    p = make_problem(G=61, B=70, H=(24, 16), seed=61)
+    x32 = p['x'].astype(np.float32)
+    out = []
+    for use_graph in (False, True):
+        _, gen, disc = _models(p)
+        T._TRACE_CONSTS.clear()
+        np.random.seed(5)
+        T.set_seed(1234)
+        go, do = T.RMSprop(5e-4), T.RMSprop(5e-4)
+        tr = T.train(x32, p['cc'], _f32(p, 'nc'), p['Z'], 3, 32, gen, disc, lambda g: 0.0, lambda: None, gen_opt=go,
+                     disc_opt=do, verbose=False, p_aug=p_aug, use_graph=use_graph)
+        out.append((gen.get_weights(), disc.get_weights(), tr, do.state_arrays(disc)['rms'], T._rng.offset))
+    (gw0, dw0, tr0, r0, o0), (gw1, dw1, tr1, r1, o1) = out
+    assert o0 == o1
+    for a, b in zip(gw0 + dw0 + r0, gw1 + dw1 + r1):
+        np.testing.assert_array_equal(a, b)
+    assert tr0['gen_loss'] == tr1['gen_loss'] and tr0['disc_loss'] == tr1['disc_loss']

@@ -27,7 +27,7 @@ SHAPES = [(1, 1, 1), (5, 37, 16), (32, 256, 71), (33, 130, 65), (96, 64, 300), (
 
 
 @pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 0)])
-@pytest.mark.parametrize('cfg', [-1, 0, 1, 2])
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize('shape', SHAPES)
 def test_gemm_layouts_configs(gpu, layout, cfg, shape):
     from adversarial_gene_expression_amd import ops
@@ -42,9 +42,10 @@ def test_gemm_layouts_configs(gpu, layout, cfg, shape):
     assert np.all(err <= 2e-6 * _bound(A, B, ta, tb) + 1e-30)
 
 
+@pytest.mark.parametrize('cfg', [-1, 1, 3])
 @pytest.mark.parametrize('splitk', [2, 5, 64])
 @pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 0)])
-def test_gemm_splitk(gpu, layout, splitk):
+def test_gemm_splitk(gpu, layout, splitk, cfg):
     from adversarial_gene_expression_amd import ops
     ta, tb = layout
     M, N, K = 45, 70, 1111
@@ -53,7 +54,7 @@ def test_gemm_splitk(gpu, layout, splitk):
     B = rs.randn(*((N, K) if tb else (K, N))).astype(np.float32)
     bias = rs.randn(N).astype(np.float32)
     from adversarial_gene_expression_amd import _dev
-    out = ops.gemm(_dev_mat(A), _dev_mat(B), M, N, K, ta=ta, tb=tb, force_splitk=splitk, bias=_dev.to_dev(bias), act=1)
+    out = ops.gemm(_dev_mat(A), _dev_mat(B), M, N, K, ta=ta, tb=tb, force_splitk=splitk, force_cfg=cfg, bias=_dev.to_dev(bias), act=1)
     ref = np.maximum(_ref(A, B, ta, tb) + bias, 0)
     err = np.abs(out.cpu().numpy()[:, :N] - ref)
     assert np.all(err <= 2e-6 * (_bound(A, B, ta, tb) + np.abs(bias)) + 1e-30)
@@ -108,7 +109,7 @@ def test_gemm_identity_with_asymmetric_b(gpu):
     from adversarial_gene_expression_amd import ops
     n = 96
     B = (np.arange(n)[:, None] * 1000 + np.arange(n)[None, :]).astype(np.float32)
-    for cfg in (0, 1, 2):
+    for cfg in (0, 1, 2, 3):
         out = ops.gemm(_dev_mat(np.eye(n, dtype=np.float32)), _dev_mat(B), n, n, n, force_cfg=cfg)
         np.testing.assert_array_equal(out.cpu().numpy()[:, :n], B)
 
@@ -137,3 +138,26 @@ def test_gemm_gtex_shapes_bitwise_reproducible(gpu):
         assert torch.equal(y3, 2.0 * y1)   # scaling by 2 is exact in fp32
         ref = (X[:, :G + 7].double() @ W.double())
         assert float((y1[:, :H].double() - ref).abs().max()) < 5e-3  # K=18161, |sum| ~ 135
+
+
+@pytest.mark.parametrize('cfg', [2, 3])
+@pytest.mark.parametrize('M,N,K', [(5, 37, 16), (32, 1076, 128), (33, 4297, 70)])
+def test_gemm_rowscale_and_row_sum_of_squares(gpu, M, N, K, cfg):
+    """Side outputs used by the fused gradient-penalty path: per-row scaling and the deterministic
+    per-32-column-slab partial sums of squares of the stored result."""
+    from adversarial_gene_expression_amd import ops, _dev
+    rs = np.random.RandomState(N)
+    A, B = rs.randn(M, K).astype(np.float32), rs.randn(N, K).astype(np.float32)
+    scale = rs.randn(M).astype(np.float32)
+    nslab = (N + 31) // 32
+    sq = _dev.zeros((M, nslab + 2))
+    sd = _dev.to_dev(scale)
+    out = ops.gemm(_dev_mat(A), _dev_mat(B), M, N, K, tb=1, rowscale=sd, rowsq=sq, force_cfg=cfg)
+    ref = scale[:, None].astype(np.float64) * (A.astype(np.float64) @ B.T)
+    got = out.cpu().numpy()[:, :N]
+    np.testing.assert_allclose(got, ref, atol=3e-5)
+    want_sq = np.stack([np.sum(got[:, 32 * s:32 * s + 32].astype(np.float64) ** 2, axis=1) for s in range(nslab)], 1)
+    np.testing.assert_allclose(sq.cpu().numpy()[:, :nslab], want_sq, rtol=2e-6, atol=1e-12)
+    sq2 = _dev.zeros((M, nslab + 2))
+    ops.gemm(_dev_mat(A), _dev_mat(B), M, N, K, tb=1, rowscale=sd, rowsq=sq2, force_cfg=cfg)
+    assert torch.equal(sq, sq2)   # fixed summation order

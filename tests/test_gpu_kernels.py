@@ -198,3 +198,38 @@ def test_rng_streams(gpu):
     assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 5e-3
     odd = ops.rng(5, 1, 0, True).cpu().numpy()           # ragged tail of a 4-wide counter block
     assert np.all(np.isfinite(odd))
+
+
+def test_critic_head_and_gp_finalize(gpu):
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    rs = np.random.RandomState(8)
+    B, H = 7, 48
+    R = 3 * B
+    A = rs.randn(R, H).astype(np.float32)
+    w, b = rs.randn(H).astype(np.float32), np.array([-0.2], np.float32)
+    Ad, wd, bd = _dev.to_dev(A), _dev.to_dev(w), _dev.to_dev(b)
+    out, d = _dev.empty(R), _dev.empty((R, H))
+    inv = 1.0 / B
+    _lib.check(lib.agx_critic_head(_dev.stream(), ptr(Ad), H, ptr(wd), ptr(bd), ptr(out), ptr(d), H, R, H, B, B,
+                                   -inv, inv, 1.0, 0.0))
+    np.testing.assert_allclose(out.cpu().numpy(), A.astype(np.float64) @ w - 0.2, atol=2e-5)
+    c = np.concatenate([np.full(B, -inv), np.full(B, inv), np.ones(B)]).astype(np.float32)
+    np.testing.assert_allclose(d.cpu().numpy(), np.where(A > 0, 1.0, 0.0) * (c[:, None] * w[None, :]), rtol=1e-6, atol=1e-9)
+    # finalisation from per-slab partial sums
+    nslab, ncov, ldx = 11, 7, 20
+    part = rs.rand(B, nslab).astype(np.float32)
+    d1 = rs.randn(B, H).astype(np.float32)
+    xc = rs.randn(B, ldx).astype(np.float32)
+    pd, d1d, xcd = _dev.to_dev(part), _dev.to_dev(d1), _dev.to_dev(xc)
+    slopes, fs = _dev.empty(B), _dev.empty(B)
+    coef = 10.0 * 2.0 / B
+    _lib.check(lib.agx_gp_finalize(_dev.stream(), ptr(pd), nslab, nslab, ptr(slopes), ptr(fs), ptr(d1d), H, H,
+                                   xcd.data_ptr() + 4 * 3, ldx, ncov, B, coef))
+    s = np.sqrt(part.astype(np.float64).sum(1))
+    f = coef * (s - 1) / s
+    np.testing.assert_allclose(slopes.cpu().numpy(), s, rtol=2e-6)
+    np.testing.assert_allclose(fs.cpu().numpy(), f, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(d1d.cpu().numpy(), d1 * f[:, None], rtol=2e-5, atol=1e-7)
+    got = xcd.cpu().numpy()
+    assert np.all(got[:, 3:3 + ncov] == 0) and np.array_equal(got[:, :3], xc[:, :3]) and np.array_equal(got[:, 10:], xc[:, 10:])
