@@ -42,6 +42,8 @@ class GemmDesc(C.Structure):
         ('force_splitk', C.c_int32),
         ('prof_id', C.c_int32),
         ('prof_tagged', C.c_int32),
+        ('interp_rows', C.c_int32),
+        ('interp_alpha', C.c_void_p),
     ]
 
 
@@ -73,6 +75,7 @@ class CganConfig(C.Structure):
         ('gen', MlpDesc), ('disc', MlpDesc),
         ('slope', C.c_float),
         ('max_batch', C.c_int32),
+        ('max_steps', C.c_int32),
     ]
 
 
@@ -96,6 +99,34 @@ class IterArgs(C.Structure):
         ('seed', C.c_uint64),
         ('aug_mask_disc', C.c_void_p), ('aug_noise_fake', C.c_void_p), ('aug_noise_real', C.c_void_p),
         ('aug_mask_gen', C.c_void_p), ('aug_noise_gen', C.c_void_p),
+    ]
+
+
+class RngSeg(C.Structure):
+    _fields_ = [('out', C.c_void_p), ('n', C.c_int64), ('sub_offset', C.c_uint64), ('normal', C.c_int32)]
+
+
+class SmallGrads(C.Structure):
+    _fields_ = [
+        ('n_colsum', C.c_int32),
+        ('cs_A', C.c_void_p * AGX_MAX_LAYERS),
+        ('cs_lda', C.c_int32 * AGX_MAX_LAYERS), ('cs_r0', C.c_int32 * AGX_MAX_LAYERS),
+        ('cs_r1', C.c_int32 * AGX_MAX_LAYERS), ('cs_H', C.c_int32 * AGX_MAX_LAYERS),
+        ('cs_out', C.c_void_p * AGX_MAX_LAYERS),
+        ('w_A', C.c_void_p),
+        ('w_lda', C.c_int32), ('w_R', C.c_int32), ('w_H', C.c_int32), ('w_n0', C.c_int32), ('w_n1', C.c_int32),
+        ('w_c0', C.c_float), ('w_c1', C.c_float), ('w_c2', C.c_float),
+        ('w_out', C.c_void_p), ('w_bias_out', C.c_void_p),
+        ('emb_grad', C.c_void_p),
+        ('emb', EmbedDesc),
+        ('emb_D', C.c_void_p), ('emb_W', C.c_void_p),
+        ('emb_cat', C.c_void_p),
+        ('emb_ldd', C.c_int32), ('emb_H', C.c_int32), ('emb_ldw', C.c_int32), ('emb_col0', C.c_int32),
+        ('emb_ld_cat', C.c_int32), ('emb_B', C.c_int32), ('emb_rows', C.c_int32),
+        ('l_losses', C.c_void_p),
+        ('l_out', C.c_void_p), ('l_slopes', C.c_void_p),
+        ('l_n0', C.c_int32), ('l_n1', C.c_int32), ('l_ns', C.c_int32),
+        ('l_inv_b', C.c_float), ('l_gp_weight', C.c_float), ('l_fake_sign', C.c_float),
     ]
 
 
@@ -134,6 +165,10 @@ SIGNATURES = {
     'agx_rng_uniform': (C.c_int, [_vp, _vp, _i64, _u64, _u64]),
     'agx_rng_at': (C.c_int, [_vp, _vp, _i64, _u64, _vp, _u64, _i32]),
     'agx_set_u64': (C.c_int, [_vp, _vp, _u64]),
+    'agx_rng_multi': (C.c_int, [_vp, _u64, _vp, _i32, C.POINTER(RngSeg)]),
+    'agx_stack_rows': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32,
+                                 _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32]),
+    'agx_small_grads': (C.c_int, [_vp, C.POINTER(SmallGrads)]),
     'agx_colstats': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     'agx_standardize': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
     'agx_corr_xtx': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i64, _i64]),

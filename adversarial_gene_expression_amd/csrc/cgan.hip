@@ -20,6 +20,13 @@
 //   rows of W_1 (ReLU masks are piecewise constant): the covariate columns of
 //   the inter rows are zeroed before the dW_1 product and bias gradients sum
 //   rows 0..2B only.
+// * The first Dense layer is linear, so its pre-activation on the interpolated rows
+//   real + alpha*(fake-real) (tf_utils.py:162-167) is r + alpha*(f - r) of the pre-activations of
+//   the real and fake rows: layer 1 runs on 2B rows and the split-K reduce emits the third block
+//   (agx_gemm_t.interp_rows) - the interpolated INPUT is never materialised.
+// * Inside a captured iteration the generator weights are constant over the nb_critic critic
+//   steps and the generator step (they change only at the iteration's end), so the generator
+//   runs ONCE on the nb_critic+1 stacked z batches; each step picks up its block of fake rows.
 #include "agx_common.h"
 
 #include <algorithm>
@@ -32,7 +39,7 @@ struct agx_cgan {
   bool bound = false;
   float *gp = nullptr, *gg = nullptr, *dp = nullptr, *dg = nullptr;  // flat params / grads
   // workspace views
-  int Bm = 0, G = 0, Dd = 0, Dg = 0, ldx = 0, ldg0 = 0, ldcov = 0, ncov = 0;
+  int Bm = 0, S = 6, G = 0, Dd = 0, Dg = 0, ldx = 0, ldg0 = 0, ncov = 0;
   float *X = nullptr;                       // [3Bm, ldx] stacked critic input (+cov cols)
   float *A[AGX_MAX_LAYERS + 1] = {};        // critic activations  [3Bm, ldh]
   float *D[AGX_MAX_LAYERS + 1] = {};        // critic deltas       [3Bm, ldh]
@@ -40,10 +47,10 @@ struct agx_cgan {
   float *out = nullptr, *slopes = nullptr;  // [3Bm], [Bm]
   float *fscale = nullptr, *rowsq = nullptr;  // [Bm], [Bm, nslab]
   int nslab = 0;
-  float *dcov = nullptr;                    // [2Bm, ldcov]
-  float *gin0 = nullptr, *gdin0 = nullptr;  // [Bm, ldg0]
-  float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [Bm, ldgh]
-  float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas
+  float *gin0 = nullptr;                    // [S*Bm, ldg0] generator layer-1 input [z | num | emb]
+  float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [S*Bm, ldgh]
+  float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas      [Bm, ldgh]
+  float *F = nullptr;                       // [S*Bm, ldsx] fake rows of a whole captured iteration
   int ldgh[AGX_MAX_LAYERS + 1] = {};
   // staging for the captured iteration (agx_cgan_iter_*)
   float *sx = nullptr, *snum = nullptr, *zbuf = nullptr, *abuf = nullptr, *losslog = nullptr;
@@ -99,7 +106,7 @@ struct Carver {
 
 void carve(agx_cgan *h, float *base) {
   const agx_cgan_config_t &c = h->cfg;
-  const int Bm = c.max_batch;
+  const int Bm = c.max_batch, S = h->S;
   Carver cv(base);
   h->X = cv.take((int64_t)3 * Bm * h->ldx);
   const int L = c.disc.n_layers - 1;
@@ -113,21 +120,20 @@ void carve(agx_cgan *h, float *base) {
   h->fscale = cv.take(Bm);
   h->nslab = (c.x_dim + 31) / 32;
   h->rowsq = cv.take((int64_t)Bm * h->nslab);
-  h->dcov = cv.take((int64_t)2 * Bm * h->ldcov);
-  h->gin0 = cv.take((int64_t)Bm * h->ldg0);
-  h->gdin0 = cv.take((int64_t)Bm * h->ldg0);
+  h->gin0 = cv.take((int64_t)S * Bm * h->ldg0);
   const int Lg = c.gen.n_layers - 1;
   for (int l = 1; l <= Lg; ++l) {
     h->ldgh[l] = r4(c.gen.dims[l]);
-    h->gh[l] = cv.take((int64_t)Bm * h->ldgh[l]);
+    h->gh[l] = cv.take((int64_t)S * Bm * h->ldgh[l]);
     h->gd[l] = cv.take((int64_t)Bm * h->ldgh[l]);
   }
   h->ldsx = r4(c.x_dim);
+  h->F = cv.take((int64_t)S * Bm * h->ldsx);
   h->sx = cv.take((int64_t)Bm * h->ldsx);
   h->snum = cv.take((int64_t)Bm * std::max(c.gen.n_num, 1));
   h->scat = reinterpret_cast<int32_t *>(cv.take((int64_t)Bm * std::max(c.gen.emb.n_cat, 1)));
-  h->zbuf = cv.take((int64_t)Bm * c.z_dim);
-  h->abuf = cv.take(Bm);
+  h->zbuf = cv.take((int64_t)S * Bm * c.z_dim);
+  h->abuf = cv.take((int64_t)S * Bm);
   h->losslog = cv.take(4 * 64);
   h->rngpos = reinterpret_cast<uint64_t *>(cv.take(16));
   // split-K scratch: the largest request over the GEMM shapes of both steps
@@ -137,13 +143,16 @@ void carve(agx_cgan *h, float *base) {
     const int B = Bs[bi];
     for (int l = 0; l < c.disc.n_layers - 1; ++l) {
       need = std::max(need, agx_gemm_ws_floats(3 * B, c.disc.dims[l + 1], c.disc.dims[l]));
+      need = std::max(need, agx_gemm_ws_floats(2 * B, c.disc.dims[l + 1], c.disc.dims[l]));
       need = std::max(need, agx_gemm_ws_floats(B, c.disc.dims[l + 1], c.disc.dims[l]));
       need = std::max(need, agx_gemm_ws_floats(3 * B, c.disc.dims[l], c.disc.dims[l + 1]));
       need = std::max(need, agx_gemm_ws_floats(B, c.disc.dims[l], c.disc.dims[l + 1]));
       need = std::max(need, agx_gemm_ws_floats(c.disc.dims[l], c.disc.dims[l + 1], 3 * B));
     }
+    need = std::max(need, (int64_t)2 * B * c.disc.dims[1]);  // layer 1 always goes through the slab reduce
     for (int l = 0; l < c.gen.n_layers; ++l) {
       need = std::max(need, agx_gemm_ws_floats(B, c.gen.dims[l + 1], c.gen.dims[l]));
+      need = std::max(need, agx_gemm_ws_floats(S * B, c.gen.dims[l + 1], c.gen.dims[l]));
       need = std::max(need, agx_gemm_ws_floats(B, c.gen.dims[l], c.gen.dims[l + 1]));
       need = std::max(need, agx_gemm_ws_floats(c.gen.dims[l], c.gen.dims[l + 1], B));
     }
@@ -174,23 +183,29 @@ struct Gemm {  // GEMM call builder
   Gemm &mask(const float *m, int ld) { g.mask = m; g.ldmask = ld; return *this; }
   Gemm &rowscale(const float *r) { g.rowscale = r; return *this; }
   Gemm &rowsq(float *q, int ld) { g.rowsq = q; g.rowsq_ld = ld; return *this; }
+  Gemm &interp(int rows, const float *alpha) { g.interp_rows = rows; g.interp_alpha = alpha; return *this; }
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
   int run(hipStream_t st) { return agx_gemm_f32(st, &g); }
 };
 
-// generator forward; activations kept in h->gh[]; output [B, x_dim] into (out, ldo)
-int gen_forward(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, const float *num,
-                int B, float *out, int ldo) {
+// generator layer-1 input rows [0, R): [z | num | emb], covariates of source row r % B
+int gen_input(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, const float *num, int R,
+              int B) {
   const agx_mlp_desc_t &m = h->cfg.gen;
-  AGX_TRY(agx_embed_concat_fwd(st, &m.emb, h->gp, z, h->cfg.z_dim, h->cfg.z_dim, num, m.n_num,
-                               m.n_num, cat, m.emb.n_cat, B, 0, h->gin0, h->ldg0));
+  return agx_stack_rows(st, &m.emb, h->gp, z, h->cfg.z_dim, 0, R, num, m.n_num, m.n_num, cat, m.emb.n_cat,
+                        B, R, h->cfg.z_dim, h->gin0, h->ldg0, nullptr, nullptr, 0);
+}
+
+// generator Dense stack over rows [0, R) of gin0; activations kept in h->gh[]; output [R, x_dim]
+int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo) {
+  const agx_mlp_desc_t &m = h->cfg.gen;
   const float *in = h->gin0;
   int ldin = h->ldg0;
   for (int l = 0; l < m.n_layers; ++l) {
     const bool last = (l == m.n_layers - 1);
     float *o = last ? out : h->gh[l + 1];
     const int ldo_l = last ? ldo : h->ldgh[l + 1];
-    Gemm g(h, in, ldin, 0, h->gp + m.w_off[l], m.ldw[l], 0, o, ldo_l, B, m.dims[l + 1], m.dims[l]);
+    Gemm g(h, in, ldin, 0, h->gp + m.w_off[l], m.ldw[l], 0, o, ldo_l, R, m.dims[l + 1], m.dims[l]);
     g.bias(h->gp + m.b_off[l]).id(last ? AGX_K_GEN_FWD_OUT : AGX_K_GEN_FWD_HID);
     if (!last) g.act();
     AGX_TRY(g.run(st));
@@ -200,27 +215,28 @@ int gen_forward(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat,
   return AGX_OK;
 }
 
-// critic forward over R rows of h->X (gene columns already in place); fills covariate
-// columns (source rows modulo B), activations A[1..L] and scores out[R]
-int disc_forward_rows(agx_cgan *h, hipStream_t st, const int32_t *cat, const float *num, int R,
-                      int B, int n0, int n1, float c0, float c1, float c2) {
+// critic Dense stack from layer index l0 over R rows (input of layer l0 already in place),
+// then Dense(1) + seed of the backward chain D[L] = act'(A_L) * c(r) * w_out
+int disc_layers_from(agx_cgan *h, hipStream_t st, int l0, int R, int n0, int n1, float c0, float c1,
+                     float c2) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   const int L = m.n_layers - 1;
-  AGX_TRY(agx_embed_concat_fwd(st, &m.emb, h->dp, nullptr, 0, 0, num, m.n_num, m.n_num, cat,
-                               m.emb.n_cat, R, B, h->X + h->G, h->ldx));
-  const float *in = h->X;
-  int ldin = h->ldx;
-  for (int l = 0; l < L; ++l) {
+  for (int l = l0; l < L; ++l) {
+    const float *in = l == 0 ? h->X : h->A[l];
+    const int ldin = l == 0 ? h->ldx : h->ldh[l];
     Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, h->A[l + 1], h->ldh[l + 1], R,
         m.dims[l + 1], m.dims[l]);
     g.bias(h->dp + m.b_off[l]).act().id(l == 0 ? AGX_K_DISC_FWD_IN : AGX_K_DISC_FWD_HID);
     AGX_TRY(g.run(st));
-    in = h->A[l + 1];
-    ldin = h->ldh[l + 1];
   }
-  // Dense(1) + seed of the backward chain D[L] = act'(A_L) * c(r) * w_out
   return agx_critic_head(st, h->A[L], h->ldh[L], h->dp + m.w_off[L], h->dp + m.b_off[L], h->out,
                          h->D[L], h->ldh[L], R, m.dims[L], n0, n1, c0, c1, c2, h->cfg.slope);
+}
+
+int disc_cov_columns(agx_cgan *h, hipStream_t st, const int32_t *cat, const float *num, int R, int B) {
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  return agx_stack_rows(st, &m.emb, h->dp, nullptr, 0, 0, 0, num, m.n_num, m.n_num, cat, m.emb.n_cat, B, R,
+                        h->G, h->X, h->ldx, nullptr, nullptr, 0);
 }
 
 // first-order chain D[L] -> D[1] over R rows
@@ -235,6 +251,117 @@ int disc_backward_chain(agx_cgan *h, hipStream_t st, int R) {
     AGX_TRY(g.run(st));
   }
   return AGX_OK;
+}
+
+// Critic gradients given X rows [0,2B) = [real; fake] (gene + covariate columns in place).
+int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_global, const float *alpha,
+                float gp_weight, float *losses) {
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  const int L = m.n_layers - 1, R = 3 * B, G = h->G, ldx = h->ldx;
+  const float invb = 1.0f / (float)B_global;
+  float *Xi = h->X + (size_t)2 * B * ldx;
+  // layer 1 on [real; fake]; the reduce emits the interpolated rows by linearity (:162-167, :213-214)
+  AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], 2 * B, m.dims[1],
+               m.dims[0]).bias(h->dp + m.b_off[0]).act().interp(B, alpha).id(AGX_K_DISC_FWD_IN).run(st));
+  // deeper layers + Dense(1) on the 3B stacked rows, seed c = [-1/B | +1/B | 1]
+  AGX_TRY(disc_layers_from(h, st, 1, R, B, B, -invb, invb, 1.f));
+  AGX_TRY(disc_backward_chain(h, st, R));
+  // g = d_1 . W_1[:G]^T -> inter rows of X, with the per-slab row sums of squares as a side
+  // output of the epilogue                                                      :168-169
+  float *D1i = h->D[1] + (size_t)2 * B * h->ldh[1];
+  AGX_TRY(Gemm(h, D1i, h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, Xi, ldx, B, G, m.dims[1])
+              .rowsq(h->rowsq, h->nslab).id(AGX_K_DISC_DX).run(st));
+  // slopes; f = weight*(2/B)*(s-1)/s; D_1[inter] *= f (dg = f*g stays implicit); the penalty has
+  // no gradient w.r.t. the covariate rows of W_1: zero those columns of the inter rows   :169-170
+  AGX_TRY(agx_gp_finalize(st, h->rowsq, h->nslab, h->nslab, h->slopes, h->fscale, D1i, h->ldh[1],
+                          m.dims[1], Xi + G, ldx, h->ncov, B, gp_weight * 2.0f * invb));
+  // second-order chain, in place over the inter rows of the activations
+  {
+    const float *in = Xi;
+    int ldin = ldx, K = G;
+    for (int l = 0; l < L; ++l) {
+      float *Ai = h->A[l + 1] + (size_t)2 * B * h->ldh[l + 1];
+      Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, Ai, h->ldh[l + 1], B, m.dims[l + 1], K);
+      g.mask(Ai, h->ldh[l + 1]).id(l == 0 ? AGX_K_GP2_IN : AGX_K_GP2_HID);
+      if (l == 0) g.rowscale(h->fscale);  // e_1 = relu'(A_1) * ((f*g) . W_1[:G])
+      AGX_TRY(g.run(st));
+      in = Ai;
+      ldin = h->ldh[l + 1];
+      K = m.dims[l + 1];
+    }
+  }
+  // kernel gradients: one stacked product per layer (K = 3B)
+  for (int l = L - 1; l >= 0; --l) {
+    const float *in = l == 0 ? h->X : h->A[l];
+    const int ldin = l == 0 ? ldx : h->ldh[l];
+    AGX_TRY(Gemm(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l],
+              m.dims[l], m.dims[l + 1], R).id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID).run(st));
+  }
+  // everything small in one launch: bias gradients (rows 0..2B), Dense(1) gradient, embedding
+  // tables (from D_1 rows 0..2B and the covariate rows of W_1), loss scalars      :174-181, :217-218
+  agx_small_grads_t j;
+  memset(&j, 0, sizeof(j));
+  j.n_colsum = L;
+  for (int l = 0; l < L; ++l) {
+    j.cs_A[l] = h->D[l + 1]; j.cs_lda[l] = h->ldh[l + 1]; j.cs_r0[l] = 0; j.cs_r1[l] = 2 * B;
+    j.cs_H[l] = m.dims[l + 1]; j.cs_out[l] = h->dg + m.b_off[l];
+  }
+  j.w_A = h->A[L]; j.w_lda = h->ldh[L]; j.w_R = R; j.w_H = m.dims[L]; j.w_n0 = B; j.w_n1 = B;
+  j.w_c0 = -invb; j.w_c1 = invb; j.w_c2 = 1.f;
+  j.w_out = h->dg + m.w_off[L]; j.w_bias_out = h->dg + m.b_off[L];
+  if (m.emb.n_cat > 0) {
+    j.emb_grad = h->dg; j.emb = m.emb; j.emb_D = h->D[1]; j.emb_ldd = h->ldh[1]; j.emb_H = m.dims[1];
+    j.emb_W = h->dp + m.w_off[0]; j.emb_ldw = m.ldw[0]; j.emb_col0 = G + m.n_num;
+    j.emb_cat = cat; j.emb_ld_cat = m.emb.n_cat; j.emb_B = B; j.emb_rows = 2 * B;
+  }
+  j.l_losses = losses; j.l_out = h->out; j.l_slopes = h->slopes; j.l_n0 = B; j.l_n1 = B; j.l_ns = B;
+  j.l_inv_b = invb; j.l_gp_weight = gp_weight; j.l_fake_sign = 1.f;
+  return agx_small_grads(st, &j);
+}
+
+// Generator gradients given X rows [0,B) = generated rows (+covariates) and the generator
+// activations of those rows at row offset gen_row0 of gin0 / gh[].
+int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_global, int gen_row0,
+             float *losses) {
+  const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
+  const int Lg = gm.n_layers - 1, G = h->G, ldx = h->ldx;
+  const float invb = 1.0f / (float)B_global;
+  float *dX = h->X + (size_t)B * ldx;
+  // critic forward (:250) + seed -1/B of d mean(-D)/d out; critic weights untouched   :255
+  AGX_TRY(disc_layers_from(h, st, 0, B, B, 0, -invb, 0.f, 0.f));
+  AGX_TRY(disc_backward_chain(h, st, B));
+  AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1])
+              .id(AGX_K_DISC_DX).run(st));
+  // generator backward
+  agx_small_grads_t j;
+  memset(&j, 0, sizeof(j));
+  const float *dout = dX;
+  int lddout = ldx;
+  for (int l = Lg; l >= 0; --l) {
+    const float *in = l == 0 ? h->gin0 + (size_t)gen_row0 * h->ldg0 : h->gh[l] + (size_t)gen_row0 * h->ldgh[l];
+    const int ldin = l == 0 ? h->ldg0 : h->ldgh[l];
+    AGX_TRY(Gemm(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l],
+              gm.dims[l + 1], B).id(l == Lg ? AGX_K_GEN_DW_OUT : AGX_K_GEN_DW_HID).run(st));
+    j.cs_A[j.n_colsum] = dout; j.cs_lda[j.n_colsum] = lddout; j.cs_r0[j.n_colsum] = 0; j.cs_r1[j.n_colsum] = B;
+    j.cs_H[j.n_colsum] = gm.dims[l + 1]; j.cs_out[j.n_colsum] = h->gg + gm.b_off[l];
+    ++j.n_colsum;
+    if (l > 0) {
+      Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
+          gm.dims[l + 1]);
+      g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
+      AGX_TRY(g.run(st));
+      dout = h->gd[l];
+      lddout = h->ldgh[l];
+    }
+  }
+  if (gm.emb.n_cat > 0) {  // dout is now the first generator layer's delta gd[1]
+    j.emb_grad = h->gg; j.emb = gm.emb; j.emb_D = dout; j.emb_ldd = lddout; j.emb_H = gm.dims[1];
+    j.emb_W = h->gp + gm.w_off[0]; j.emb_ldw = gm.ldw[0]; j.emb_col0 = h->cfg.z_dim + gm.n_num;
+    j.emb_cat = cat; j.emb_ld_cat = gm.emb.n_cat; j.emb_B = B; j.emb_rows = B;
+  }
+  j.l_losses = losses; j.l_out = h->out; j.l_n0 = B; j.l_n1 = 0; j.l_ns = 0;   // mean(-D(fake))  :253
+  j.l_inv_b = invb; j.l_gp_weight = 0.f; j.l_fake_sign = 1.f;
+  return agx_small_grads(st, &j);
 }
 
 int check_step(const agx_cgan *h, const agx_step_args_t *a, bool critic) {
@@ -278,7 +405,8 @@ extern "C" int agx_cgan_create(const agx_cgan_config_t *cfg, agx_cgan_t **out) {
   h->ldx = r4(h->Dd);
   h->ldg0 = r4(h->Dg);
   h->ncov = h->Dd - h->G;
-  h->ldcov = r4(std::max(h->ncov, 1));
+  h->S = cfg->max_steps > 0 ? cfg->max_steps : 6;
+  AGX_CHECK_ARG(h->S <= 63, "agx_cgan_create: max_steps %d > 63", h->S);
   carve(h, nullptr);
   *out = h;
   return AGX_OK;
@@ -316,7 +444,8 @@ extern "C" int agx_cgan_gen_forward(agx_cgan_t *h, void *stream, const float *z,
   AGX_CHECK_ARG(h && z && out, "agx_cgan_gen_forward: null argument");
   if (!h->bound) { agx::set_error("agx_cgan_gen_forward: not bound"); return AGX_E_STATE; }
   AGX_CHECK_ARG(B > 0 && B <= h->Bm && ldo >= h->G, "agx_cgan_gen_forward: bad B=%d / ldo=%d", B, ldo);
-  return gen_forward(h, agx::as_stream(stream), z, cat, num, B, out, ldo);
+  AGX_TRY(gen_input(h, agx::as_stream(stream), z, cat, num, B, B));
+  return gen_layers(h, agx::as_stream(stream), B, out, ldo);
 }
 
 extern "C" int agx_cgan_disc_forward(agx_cgan_t *h, void *stream, const float *x, int32_t ldx,
@@ -327,7 +456,8 @@ extern "C" int agx_cgan_disc_forward(agx_cgan_t *h, void *stream, const float *x
   hipStream_t st = agx::as_stream(stream);
   AGX_HIP(hipMemcpy2DAsync(h->X, (size_t)h->ldx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
                            hipMemcpyDeviceToDevice, st));
-  AGX_TRY(disc_forward_rows(h, st, cat, num, B, 0, B, 0, 0.f, 0.f, 0.f));
+  AGX_TRY(disc_cov_columns(h, st, cat, num, B, B));
+  AGX_TRY(disc_layers_from(h, st, 0, B, B, 0, 0.f, 0.f, 0.f));
   AGX_HIP(hipMemcpyAsync(scores, h->out, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
   return AGX_OK;
 }
@@ -335,111 +465,30 @@ extern "C" int agx_cgan_disc_forward(agx_cgan_t *h, void *stream, const float *x
 extern "C" int agx_cgan_disc_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a) {
   AGX_TRY(check_step(h, a, true));
   hipStream_t st = agx::as_stream(stream);
-  const agx_mlp_desc_t &m = h->cfg.disc;
-  const int L = m.n_layers - 1, B = a->B, R = 3 * B, G = h->G, ldx = h->ldx;
-  const float invb = 1.0f / (float)a->B_global;
-  float *Xr = h->X, *Xf = h->X + (size_t)B * ldx, *Xi = h->X + (size_t)2 * B * ldx;
-
+  const int B = a->B, G = h->G, ldx = h->ldx;
+  float *Xr = h->X, *Xf = h->X + (size_t)B * ldx;
   // fake batch straight into rows B..2B (generator is not differentiated, tf_utils.py:206)
-  AGX_TRY(gen_forward(h, st, a->z, a->cat, a->num, B, Xf, ldx));
+  AGX_TRY(gen_input(h, st, a->z, a->cat, a->num, B, B));
+  AGX_TRY(gen_layers(h, st, B, Xf, ldx));
   AGX_HIP(hipMemcpy2DAsync(Xr, (size_t)ldx * 4, a->x, (size_t)a->ldx * 4, (size_t)G * 4, B,
                            hipMemcpyDeviceToDevice, st));
   if (a->aug_mask) {  // tf_utils.py:209-210
     AGX_TRY(agx_aug_add(st, Xf, ldx, a->aug_mask, a->aug_noise_fake, G, 1, B, G));
     AGX_TRY(agx_aug_add(st, Xr, ldx, a->aug_mask, a->aug_noise_real, G, 0, B, G));
   }
-  AGX_TRY(agx_gp_interp(st, Xr, ldx, Xf, ldx, a->alpha, Xi, ldx, B, G));  // :162-164
-  // one forward over [real; fake; inter] (:213-214, :167) + seed c = [-1/B | +1/B | 1]
-  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, R, B, B, B, -invb, invb, 1.f));
-  AGX_TRY(disc_backward_chain(h, st, R));
-  // g = d_1 . W_1[:G]^T -> inter rows of X (inter itself is dead now), with the per-slab
-  // row sums of squares as a side output of the epilogue                    :168-169
-  float *D1i = h->D[1] + (size_t)2 * B * h->ldh[1];
-  AGX_TRY(Gemm(h, D1i, h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, Xi, ldx, B, G, m.dims[1])
-              .rowsq(h->rowsq, h->nslab).id(AGX_K_DISC_DX).run(st));
-  // slopes; f = weight*(2/B)*(s-1)/s; D_1[inter] *= f (dg = f*g stays implicit); the penalty has
-  // no gradient w.r.t. the covariate rows of W_1: zero those columns of the inter rows   :169-170
-  AGX_TRY(agx_gp_finalize(st, h->rowsq, h->nslab, h->nslab, h->slopes, h->fscale, D1i, h->ldh[1],
-                          m.dims[1], Xi + G, ldx, h->ncov, B, a->gp_weight * 2.0f * invb));
-  AGX_TRY(agx_wgan_loss(st, h->out, B, B, h->slopes, B, invb, a->gp_weight, 1.f, a->losses));
-
-  // second-order chain, in place over the inter rows of the activations
-  {
-    const float *in = Xi;
-    int ldin = ldx, K = G;
-    for (int l = 0; l < L; ++l) {
-      float *Ai = h->A[l + 1] + (size_t)2 * B * h->ldh[l + 1];
-      Gemm g(h, in, ldin, 0, h->dp + m.w_off[l], m.ldw[l], 0, Ai, h->ldh[l + 1], B, m.dims[l + 1], K);
-      g.mask(Ai, h->ldh[l + 1]).id(l == 0 ? AGX_K_GP2_IN : AGX_K_GP2_HID);
-      if (l == 0) g.rowscale(h->fscale);  // e_1 = relu'(A_1) * ((f*g) . W_1[:G])
-      AGX_TRY(g.run(st));
-      in = Ai;
-      ldin = h->ldh[l + 1];
-      K = m.dims[l + 1];
-    }
-  }
-
-  // gradients.  Dense(1): dw = sum_r c(r) A'_L[r,:], db = sum c
-  AGX_TRY(agx_colsum_weighted(st, h->A[L], h->ldh[L], R, m.dims[L], B, B, -invb, invb, 1.f,
-                              h->dg + m.w_off[L], h->dg + m.b_off[L]));
-  for (int l = L - 1; l >= 0; --l) {
-    const float *in = l == 0 ? h->X : h->A[l];
-    const int ldin = l == 0 ? ldx : h->ldh[l];
-    AGX_TRY(Gemm(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l],
-              m.dims[l], m.dims[l + 1], R).id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID).run(st));
-    AGX_TRY(agx_colsum(st, h->D[l + 1], h->ldh[l + 1], 0, 2 * B, m.dims[l + 1], h->dg + m.b_off[l], 0));
-  }
-  if (m.emb.n_cat > 0) {
-    // d cov = D_1[0:2B] . W_1[G:, :]^T ; scatter-add into the tables
-    AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0] + (size_t)G * m.ldw[0], m.ldw[0], 1,
-              h->dcov, h->ldcov, 2 * B, h->ncov, m.dims[1]).id(AGX_K_DISC_DCOV).run(st));
-    AGX_TRY(agx_embed_bwd(st, &m.emb, h->dg, h->dcov, h->ldcov, m.n_num, a->cat, m.emb.n_cat, 2 * B,
-                          B, 0));
-  }
-  return AGX_OK;
+  AGX_TRY(disc_cov_columns(h, st, a->cat, a->num, 2 * B, B));
+  return critic_core(h, st, a->cat, B, a->B_global, a->alpha, a->gp_weight, a->losses);
 }
 
 extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_args_t *a) {
   AGX_TRY(check_step(h, a, false));
   hipStream_t st = agx::as_stream(stream);
-  const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
-  const int Lg = gm.n_layers - 1, B = a->B, G = h->G, ldx = h->ldx;
-  const float invb = 1.0f / (float)a->B_global;
-  float *Xg = h->X, *dX = h->X + (size_t)B * ldx;
-
-  AGX_TRY(gen_forward(h, st, a->z, a->cat, a->num, B, Xg, ldx));                    // :244
-  if (a->aug_mask) AGX_TRY(agx_aug_add(st, Xg, ldx, a->aug_mask, a->aug_noise_fake, G, 0, B, G));  // :247
-  // critic forward (:250) + seed -1/B of d mean(-D)/d out; critic weights untouched   :255
-  AGX_TRY(disc_forward_rows(h, st, a->cat, a->num, B, 0, B, 0, -invb, 0.f, 0.f));
-  AGX_TRY(agx_wgan_loss(st, h->out, B, 0, nullptr, 0, invb, 0.f, 1.f, a->losses));  // :253
-  AGX_TRY(disc_backward_chain(h, st, B));
-  AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1])
-              .id(AGX_K_DISC_DX).run(st));
-
-  // generator backward
-  const float *dout = dX;
-  int lddout = ldx;
-  for (int l = Lg; l >= 0; --l) {
-    const float *in = l == 0 ? h->gin0 : h->gh[l];
-    const int ldin = l == 0 ? h->ldg0 : h->ldgh[l];
-    AGX_TRY(Gemm(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l],
-              gm.dims[l + 1], B).id(l == Lg ? AGX_K_GEN_DW_OUT : AGX_K_GEN_DW_HID).run(st));
-    AGX_TRY(agx_colsum(st, dout, lddout, 0, B, gm.dims[l + 1], h->gg + gm.b_off[l], 0));
-    if (l > 0) {
-      Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
-          gm.dims[l + 1]);
-      g.mask(h->gh[l], h->ldgh[l]).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
-      AGX_TRY(g.run(st));
-      dout = h->gd[l];
-      lddout = h->ldgh[l];
-    } else if (gm.emb.n_cat > 0) {
-      AGX_TRY(Gemm(h, dout, lddout, 0, h->gp + gm.w_off[0], gm.ldw[0], 1, h->gdin0, h->ldg0, B,
-                gm.dims[0], gm.dims[1]).id(AGX_K_GEN_BWD_HID).run(st));
-      AGX_TRY(agx_embed_bwd(st, &gm.emb, h->gg, h->gdin0, h->ldg0, h->cfg.z_dim + gm.n_num, a->cat,
-                            gm.emb.n_cat, B, 0, 0));
-    }
-  }
-  return AGX_OK;
+  const int B = a->B, G = h->G, ldx = h->ldx;
+  AGX_TRY(gen_input(h, st, a->z, a->cat, a->num, B, B));
+  AGX_TRY(gen_layers(h, st, B, h->X, ldx));                                                    // :244
+  if (a->aug_mask) AGX_TRY(agx_aug_add(st, h->X, ldx, a->aug_mask, a->aug_noise_fake, G, 0, B, G));  // :247
+  AGX_TRY(disc_cov_columns(h, st, a->cat, a->num, B, B));
+  return gen_core(h, st, a->cat, B, a->B_global, 0, a->losses);
 }
 
 
@@ -458,27 +507,48 @@ namespace {
 inline uint64_t r4u(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
 
 int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int64_t *draws) {
-  const int B = a->B, Z = h->cfg.z_dim;
+  const int B = a->B, Z = h->cfg.z_dim, nbc = a->nb_critic, S = nbc + 1, G = h->G;
+  const agx_mlp_desc_t &dm = h->cfg.disc;
+  // every draw of the iteration in one launch (per 16 segments), at the stream positions the eager
+  // entry points use: z_k then alpha_k per critic step, then the generator step's z
+  agx_rng_seg_t segs[AGX_MAX_RNG_SEGS];
+  int ns = 0;
   uint64_t sub = 0;
-  agx_step_args_t s;
-  memset(&s, 0, sizeof(s));
-  s.x = h->sx; s.ldx = h->ldsx; s.z = h->zbuf; s.cat = h->scat; s.num = h->snum; s.alpha = h->abuf;
-  s.B = B; s.B_global = B; s.gp_weight = a->gp_weight;
-  for (int k = 0; k < a->nb_critic; ++k) {
-    AGX_TRY(agx_rng_at(st, h->zbuf, (int64_t)B * Z, a->seed, h->rngpos, sub, 1));
+  auto flush = [&]() -> int {
+    int rc = ns ? agx_rng_multi(st, a->seed, h->rngpos, ns, segs) : AGX_OK;
+    ns = 0;
+    return rc;
+  };
+  for (int k = 0; k <= nbc; ++k) {
+    if (ns + 2 > AGX_MAX_RNG_SEGS) AGX_TRY(flush());
+    segs[ns++] = agx_rng_seg_t{h->zbuf + (size_t)k * B * Z, (int64_t)B * Z, sub, 1};
     sub += r4u((uint64_t)B * Z);
-    AGX_TRY(agx_rng_at(st, h->abuf, B, a->seed, h->rngpos, sub, 0));
-    sub += r4u((uint64_t)B);
-    s.aug_mask = a->aug_mask_disc; s.aug_noise_fake = a->aug_noise_fake; s.aug_noise_real = a->aug_noise_real;
-    s.losses = h->losslog + 4 * k;
-    AGX_TRY(agx_cgan_disc_grads(h, st, &s));
+    if (k < nbc) {
+      segs[ns++] = agx_rng_seg_t{h->abuf + (size_t)k * B, (int64_t)B, sub, 0};
+      sub += r4u((uint64_t)B);
+    }
+  }
+  AGX_TRY(flush());
+  // ONE generator forward for all nb_critic+1 z batches (generator weights are constant until the
+  // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
+  AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
+  AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx));
+  // real rows stay in X[0:B] for all critic steps (augmentation noise is a trace constant, :210)
+  AGX_HIP(hipMemcpy2DAsync(h->X, (size_t)h->ldx * 4, h->sx, (size_t)h->ldsx * 4, (size_t)G * 4, B,
+                           hipMemcpyDeviceToDevice, st));
+  if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, h->X, h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
+  for (int k = 0; k < nbc; ++k) {
+    // fake rows of this step (+ :209 noise row) into X[B:2B]; covariate columns from the CURRENT tables
+    AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)k * B * h->ldsx, h->ldsx, B, B, h->snum, dm.n_num,
+                           dm.n_num, h->scat, dm.emb.n_cat, B, 2 * B, G, h->X, h->ldx, a->aug_mask_disc,
+                           a->aug_noise_fake, 0));
+    AGX_TRY(critic_core(h, st, h->scat, B, B, h->abuf + (size_t)k * B, a->gp_weight, h->losslog + 4 * k));
     AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
   }
-  AGX_TRY(agx_rng_at(st, h->zbuf, (int64_t)B * Z, a->seed, h->rngpos, sub, 1));
-  sub += r4u((uint64_t)B * Z);
-  s.aug_mask = a->aug_mask_gen; s.aug_noise_fake = a->aug_noise_gen; s.aug_noise_real = nullptr;
-  s.losses = h->losslog + 4 * a->nb_critic;
-  AGX_TRY(agx_cgan_gen_grads(h, st, &s));
+  AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)nbc * B * h->ldsx, h->ldsx, 0, B, h->snum, dm.n_num,
+                         dm.n_num, h->scat, dm.emb.n_cat, B, B, G, h->X, h->ldx, a->aug_mask_gen,
+                         a->aug_noise_gen, G));
+  AGX_TRY(gen_core(h, st, h->scat, B, B, nbc * B, h->losslog + 4 * nbc));
   AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
   *draws = (int64_t)sub;
   return AGX_OK;
@@ -490,7 +560,7 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   AGX_CHECK_ARG(h && a && out, "agx_cgan_iter_capture: null argument");
   if (!h->bound) { agx::set_error("agx_cgan_iter_capture: not bound"); return AGX_E_STATE; }
   AGX_CHECK_ARG(a->B > 0 && a->B <= h->Bm, "agx_cgan_iter_capture: batch %d outside (0, %d]", a->B, h->Bm);
-  AGX_CHECK_ARG(a->nb_critic >= 0 && a->nb_critic < 63, "agx_cgan_iter_capture: nb_critic %d", a->nb_critic);
+  AGX_CHECK_ARG(a->nb_critic >= 0 && a->nb_critic < h->S, "agx_cgan_iter_capture: nb_critic %d needs max_steps > %d (have %d)", a->nb_critic, a->nb_critic, h->S);
   AGX_CHECK_ARG(a->disc_rms && a->gen_rms, "agx_cgan_iter_capture: optimizer slots missing");
   AGX_CHECK_ARG(!a->aug_mask_disc || (a->aug_noise_fake && a->aug_noise_real), "agx_cgan_iter_capture: critic aug noise missing");
   AGX_CHECK_ARG(!a->aug_mask_gen || a->aug_noise_gen, "agx_cgan_iter_capture: generator aug noise missing");

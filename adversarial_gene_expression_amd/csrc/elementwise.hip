@@ -353,16 +353,13 @@ __device__ __forceinline__ float u01(unsigned x) {  // [0,1) with 24 random bits
 
 __global__ void set_u64_kernel(unsigned long long *dst, unsigned long long v) { *dst = v; }
 
+// elements 4q..4q+3 of the (seed, offset)-keyed stream; NORMAL: Box-Muller, else U[0,1)
 template <bool NORMAL>
-__global__ void __launch_bounds__(256) rng_kernel(float *__restrict__ out, long long n,
-                                                  unsigned long long seed,
-                                                  unsigned long long offset,
-                                                  const unsigned long long *__restrict__ base_dev) {
-  if (base_dev) offset += *base_dev;  // device-resident stream position (graph replay)
+__device__ __forceinline__ void rng_fill(float *__restrict__ out, long long n, unsigned long long seed,
+                                         unsigned long long offset, long long q0, long long qstride) {
   // counter block q produces elements 4q .. 4q+3 of the (seed, offset)-keyed stream
   const long long nq = (n + 3) >> 2;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
-       q += (long long)gridDim.x * blockDim.x) {
+  for (long long q = q0; q < nq; q += qstride) {
     const unsigned long long ctr = (offset >> 2) + (unsigned long long)q;
     unsigned r[4];
     philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)(offset & 3u), NORMAL ? 1u : 0u,
@@ -383,6 +380,221 @@ __global__ void __launch_bounds__(256) rng_kernel(float *__restrict__ out, long 
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (4 * q + k < n) out[4 * q + k] = v[k];
+  }
+}
+
+template <bool NORMAL>
+__global__ void __launch_bounds__(256) rng_kernel(float *__restrict__ out, long long n,
+                                                  unsigned long long seed,
+                                                  unsigned long long offset,
+                                                  const unsigned long long *__restrict__ base_dev) {
+  if (base_dev) offset += *base_dev;  // device-resident stream position (graph replay)
+  rng_fill<NORMAL>(out, n, seed, offset, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                   (long long)gridDim.x * blockDim.x);
+}
+
+// several stream segments in one launch: blockIdx.y = segment (out may be strided: rows of
+// `row_len` values at leading dimension `ld`, e.g. z written straight into the layer-1 input)
+struct RngSegs {
+  int n;
+  agx_rng_seg_t seg[AGX_MAX_RNG_SEGS];
+};
+__global__ void __launch_bounds__(256) rng_multi_kernel(const RngSegs segs, unsigned long long seed,
+                                                        const unsigned long long *__restrict__ base_dev) {
+  const agx_rng_seg_t sg = segs.seg[blockIdx.y];
+  unsigned long long offset = sg.sub_offset + (base_dev ? *base_dev : 0ull);
+  const long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long qs = (long long)gridDim.x * blockDim.x;
+  if (sg.normal) rng_fill<true>(sg.out, sg.n, seed, offset, q0, qs);
+  else rng_fill<false>(sg.out, sg.n, seed, offset, q0, qs);
+}
+
+// ---------------------------------------------------------------------------
+// stacked critic input: gene columns of one row block + covariate columns of the leading rows
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stack_rows_kernel(
+    agx_embed_t e, const float *__restrict__ tables, const float *__restrict__ src, int lds,
+    int dst_row0, int src_rows, const float *__restrict__ num, int n_num, int ld_num,
+    const int *__restrict__ cat, int ld_cat, int B, int rows_cov, int G, float *__restrict__ X, int ldx,
+    const float *__restrict__ aug_mask, const float *__restrict__ aug_noise, int aug_ldn, int ncov,
+    int gene_blocks) {
+  if ((int)blockIdx.x < gene_blocks) {
+    if (!src) return;
+    const int b = blockIdx.y;
+    if (b >= src_rows) return;
+    const float m = aug_mask ? aug_mask[b] : 0.f;
+    const float *s = src + (size_t)b * lds;
+    const float *nz = aug_mask ? aug_noise + (size_t)b * aug_ldn : nullptr;
+    float *d = X + (size_t)(dst_row0 + b) * ldx;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gene_blocks * blockDim.x) {
+      float v = s[g];
+      if (aug_mask) v = v + m * nz[g];  // tf_utils.py:209-210, :247
+      d[g] = v;
+    }
+    return;
+  }
+  // covariate columns [G, G+ncov) of rows [0, rows_cov): [num | emb_0 | emb_1 ...] of source row r % B
+  const int nb = gridDim.x - gene_blocks;
+  const long long total = (long long)rows_cov * ncov;
+  for (long long idx = ((long long)(blockIdx.y * nb + (blockIdx.x - gene_blocks))) * blockDim.x + threadIdx.x;
+       idx < total; idx += (long long)nb * gridDim.y * blockDim.x) {
+    const int r = (int)(idx / ncov);
+    const int b = r % B;
+    int c = (int)(idx % ncov);
+    float v = 0.f;
+    if (c < n_num) {
+      v = num[(size_t)b * ld_num + c];
+    } else {
+      c -= n_num;
+      for (int i = 0; i < e.n_cat; ++i) {
+        if (c < e.edim[i]) {
+          const int row = cat[(size_t)b * ld_cat + i];
+          if (row >= 0 && row < e.vocab[i]) v = tables[e.table_off[i] + (size_t)row * e.edim[i] + c];
+          break;
+        }
+        c -= e.edim[i];
+      }
+    }
+    X[(size_t)r * ldx + G + (int)(idx % ncov)] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// every small gradient piece of a step in ONE launch (1024-thread blocks):
+//   blocks [0, cs_end)        column sums (BiasAddGrad) of up to AGX_MAX_LAYERS deltas
+//   blocks [cs_end, w_end)    weighted column sums = Dense(1) kernel/bias gradient
+//   blocks [w_end, emb_end)   embedding-table gradients straight from the first-layer deltas:
+//                             dE_i[v,d] = (sum_{rows r: cat[r % B, i] == v} D[r,:]) . W[col0+off_i+d, :]
+//   block  emb_end            the loss scalars (tf_utils.py:140-181)
+// Fixed summation orders: deterministic.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void colsum_block(const float *__restrict__ A, int lda, int r0, int r1, int H,
+                                             float *__restrict__ out, int blk, int weighted, int n0,
+                                             int n1, float c0, float c1, float c2,
+                                             float *__restrict__ bias_out, float (*red)[64]) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blk * 64 + tx;
+  float s = 0.f;
+  if (j < H) {
+    for (int r = r0 + ty; r < r1; r += 16) {
+      float v = A[(size_t)r * lda + j];
+      if (weighted) v *= (r < n0 ? c0 : (r < n0 + n1 ? c1 : c2));
+      s += v;
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][tx];
+    out[j] = t;
+  }
+  if (weighted && bias_out && blk == 0 && threadIdx.x == 0) bias_out[0] = (float)n0 * c0 + (float)n1 * c1;
+}
+
+__global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j) {
+  __shared__ float red[16][64];
+  __shared__ float svec[4096];
+  int blk = blockIdx.x;
+  for (int c = 0; c < j.n_colsum; ++c) {
+    const int nb = (j.cs_H[c] + 63) / 64;
+    if (blk < nb) {
+      colsum_block(j.cs_A[c], j.cs_lda[c], j.cs_r0[c], j.cs_r1[c], j.cs_H[c], j.cs_out[c], blk, 0, 0, 0,
+                   0.f, 0.f, 0.f, nullptr, red);
+      return;
+    }
+    blk -= nb;
+  }
+  if (j.w_A) {
+    const int nb = (j.w_H + 63) / 64;
+    if (blk < nb) {
+      colsum_block(j.w_A, j.w_lda, 0, j.w_R, j.w_H, j.w_out, blk, 1, j.w_n0, j.w_n1, j.w_c0, j.w_c1,
+                   j.w_c2, j.w_bias_out, red);
+      return;
+    }
+    blk -= nb;
+  }
+  if (j.emb_grad) {
+    int rows = 0;
+    for (int i = 0; i < j.emb.n_cat; ++i) rows += j.emb.vocab[i];
+    if (blk < rows) {
+      int rowid = blk, i = 0, coff = j.emb_col0;
+      while (rowid >= j.emb.vocab[i]) {
+        rowid -= j.emb.vocab[i];
+        coff += j.emb.edim[i];
+        ++i;
+      }
+      const int H = j.emb_H;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      float *part = svec, *sfin = svec + 1024;
+      // s[k] = sum over the matching rows of D[r,k]; narrow layers split the rows over 1024/Hp
+      // thread groups whose partials meet in LDS in a fixed order
+      if (H <= 512) {
+        const int Hp = (H + 63) & ~63, ng = 1024 / Hp;
+        const int kk = threadIdx.x % Hp, rg = threadIdx.x / Hp;
+        float sk = 0.f;
+        if (rg < ng && kk < H) {
+          for (int r = rg; r < j.emb_rows; r += ng)
+            if (j.emb_cat[(size_t)(r % j.emb_B) * j.emb_ld_cat + i] == rowid) sk += j.emb_D[(size_t)r * j.emb_ldd + kk];
+        }
+        if (rg < ng) part[rg * Hp + kk] = sk;
+        __syncthreads();
+        if ((int)threadIdx.x < H) {
+          float t = 0.f;
+          for (int g = 0; g < ng; ++g) t += part[g * Hp + threadIdx.x];
+          sfin[threadIdx.x] = t;
+        }
+      } else {
+        for (int k = threadIdx.x; k < H; k += 1024) {
+          float sk = 0.f;
+          for (int r = 0; r < j.emb_rows; ++r)
+            if (j.emb_cat[(size_t)(r % j.emb_B) * j.emb_ld_cat + i] == rowid) sk += j.emb_D[(size_t)r * j.emb_ldd + k];
+          sfin[k] = sk;
+        }
+      }
+      __syncthreads();
+      // dot with the edim_i kernel rows that the embedding columns feed
+      for (int d = 0; d < j.emb.edim[i]; ++d) {
+        const float *w = j.emb_W + (size_t)(coff + d) * j.emb_ldw;
+        float v = 0.f;
+        for (int k = threadIdx.x; k < H; k += 1024) v += sfin[k] * w[k];
+        v = wave_sum(v);
+        if (lane == 0) red[0][wave] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float t = 0.f;
+          for (int w16 = 0; w16 < 16; ++w16) t += red[0][w16];
+          j.emb_grad[j.emb.table_off[i] + (size_t)rowid * j.emb.edim[i] + d] = t;
+        }
+        __syncthreads();
+      }
+      return;
+    }
+    blk -= rows;
+  }
+  if (j.l_losses && blk == 0) {
+    float sr = 0.f, sf = 0.f, sg = 0.f;
+    for (int i = threadIdx.x; i < j.l_n0; i += blockDim.x) sr += j.l_out[i];
+    for (int i = threadIdx.x; i < j.l_n1; i += blockDim.x) sf += j.l_out[j.l_n0 + i];
+    for (int i = threadIdx.x; i < j.l_ns; i += blockDim.x) {
+      const float d = j.l_slopes[i] - 1.f;
+      sg += d * d;
+    }
+    sr = wave_sum(sr); sf = wave_sum(sf); sg = wave_sum(sg);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = sr; red[1][wave] = sf; red[2][wave] = sg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float r = 0.f, f = 0.f, g = 0.f;
+      for (int w = 0; w < 16; ++w) { r += red[0][w]; f += red[1][w]; g += red[2][w]; }
+      const float wl = -r * j.l_inv_b + j.l_fake_sign * f * j.l_inv_b;
+      const float gp = g * j.l_inv_b;
+      j.l_losses[0] = wl;
+      j.l_losses[1] = gp;
+      j.l_losses[2] = wl + j.l_gp_weight * gp;
+      j.l_losses[3] = 0.f;
+    }
   }
 }
 
@@ -608,6 +820,83 @@ extern "C" int agx_set_u64(void *stream, uint64_t *dst, uint64_t value) {
   AGX_CHECK_ARG(dst, "agx_set_u64: null");
   hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, agx::as_stream(stream),
                      (unsigned long long *)dst, (unsigned long long)value);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_dev, int32_t n_seg,
+                             const agx_rng_seg_t *segs) {
+  AGX_CHECK_ARG(n_seg >= 0 && n_seg <= AGX_MAX_RNG_SEGS && (n_seg == 0 || segs), "agx_rng_multi: bad segment list");
+  if (n_seg == 0) return AGX_OK;
+  RngSegs rs;
+  rs.n = n_seg;
+  long long nmax = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    AGX_CHECK_ARG(segs[i].out && segs[i].n >= 0, "agx_rng_multi: segment %d", i);
+    rs.seg[i] = segs[i];
+    nmax = std::max<long long>(nmax, segs[i].n);
+  }
+  for (int i = n_seg; i < AGX_MAX_RNG_SEGS; ++i) rs.seg[i] = segs[0];
+  hipLaunchKernelGGL(rng_multi_kernel, dim3(grid_for((nmax + 3) / 4, 256, 256), n_seg), dim3(256), 0,
+                     agx::as_stream(stream), rs, (unsigned long long)seed,
+                     (const unsigned long long *)base_dev);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_stack_rows(void *stream, const agx_embed_t *e, const float *tables, const float *src,
+                              int32_t lds, int32_t dst_row0, int32_t src_rows, const float *num, int32_t n_num,
+                              int32_t ld_num, const int32_t *cat, int32_t ld_cat, int32_t B,
+                              int32_t rows_cov, int32_t G, float *X, int32_t ldx, const float *aug_mask,
+                              const float *aug_noise, int32_t aug_ldn) {
+  AGX_CHECK_ARG(e && X && B > 0 && G > 0 && rows_cov >= 0 && dst_row0 >= 0, "agx_stack_rows: bad argument");
+  AGX_CHECK_ARG(e->n_cat >= 0 && e->n_cat <= AGX_MAX_CAT, "agx_stack_rows: n_cat %d", e->n_cat);
+  AGX_CHECK_ARG(!src || lds >= G, "agx_stack_rows: lds < G");
+  AGX_CHECK_ARG(!aug_mask || aug_noise, "agx_stack_rows: aug noise missing");
+  AGX_CHECK_ARG(!src || (src_rows > 0 && src_rows <= 65535), "agx_stack_rows: src_rows %d outside (0, 65535]", src_rows);
+  AGX_CHECK_ARG(!aug_mask || src_rows <= B, "agx_stack_rows: augmentation needs src_rows <= B");
+  int ncov = n_num;
+  for (int i = 0; i < e->n_cat; ++i) ncov += e->edim[i];
+  AGX_CHECK_ARG(ldx >= G + ncov, "agx_stack_rows: ldx %d < G + covariates %d", ldx, G + ncov);
+  AGX_CHECK_ARG(n_num == 0 || num, "agx_stack_rows: num missing");
+  AGX_CHECK_ARG(e->n_cat == 0 || (cat && tables && ld_cat >= e->n_cat), "agx_stack_rows: cat/tables missing");
+  const int gene_blocks = src ? std::min(agx::cdiv(G, 256), 32) : 0;
+  const int cov_blocks = (rows_cov > 0 && ncov > 0) ? 1 : 0;
+  if (gene_blocks + cov_blocks == 0) return AGX_OK;
+  hipLaunchKernelGGL(stack_rows_kernel, dim3(gene_blocks + cov_blocks, src ? src_rows : std::min(std::max(rows_cov, 1), 64)),
+                     dim3(256), 0, agx::as_stream(stream), *e, tables, src, lds, dst_row0, src_rows, num, n_num, ld_num, cat,
+                     ld_cat, B, cov_blocks ? rows_cov : 0, G, X, ldx, aug_mask, aug_noise, aug_ldn, ncov,
+                     gene_blocks);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_small_grads(void *stream, const agx_small_grads_t *j) {
+  AGX_CHECK_ARG(j && j->n_colsum >= 0 && j->n_colsum <= AGX_MAX_LAYERS, "agx_small_grads: bad job list");
+  int blocks = 0;
+  for (int c = 0; c < j->n_colsum; ++c) {
+    AGX_CHECK_ARG(j->cs_A[c] && j->cs_out[c] && j->cs_lda[c] >= j->cs_H[c] && j->cs_r0[c] >= 0 &&
+                      j->cs_r1[c] >= j->cs_r0[c] && j->cs_H[c] > 0, "agx_small_grads: colsum job %d", c);
+    blocks += agx::cdiv(j->cs_H[c], 64);
+  }
+  if (j->w_A) {
+    AGX_CHECK_ARG(j->w_out && j->w_lda >= j->w_H && j->w_H > 0 && j->w_R >= 0, "agx_small_grads: weighted colsum job");
+    blocks += agx::cdiv(j->w_H, 64);
+  }
+  if (j->emb_grad) {
+    AGX_CHECK_ARG(j->emb.n_cat > 0 && j->emb.n_cat <= AGX_MAX_CAT && j->emb_D && j->emb_W && j->emb_cat &&
+                      j->emb_B > 0 && j->emb_rows >= 0 && j->emb_ldd >= j->emb_H && j->emb_ldw >= j->emb_H &&
+                      j->emb_ld_cat >= j->emb.n_cat && j->emb_H <= 3072, "agx_small_grads: embedding job");
+    for (int i = 0; i < j->emb.n_cat; ++i) {
+      blocks += j->emb.vocab[i];
+    }
+  }
+  if (j->l_losses) {
+    AGX_CHECK_ARG(j->l_out && (j->l_ns == 0 || j->l_slopes), "agx_small_grads: loss job");
+    blocks += 1;
+  }
+  if (blocks == 0) return AGX_OK;
+  hipLaunchKernelGGL(small_grads_kernel, dim3(blocks), dim3(1024), 0, agx::as_stream(stream), *j);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

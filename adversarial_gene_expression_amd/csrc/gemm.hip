@@ -42,6 +42,9 @@ struct KParams {
   int rowsq_ld;
   float *ws;
   int splitk, kchunk;
+  int to_ws;              // 1: the main kernel stores raw partial slabs (also when splitk == 1)
+  int interp_rows;        // R > 0: M == 2R rows are [real; fake]; the reduce emits rows [2R,3R) too
+  const float *interp_alpha;
   // SYRK only
   long long tile_begin;
   int tiles_1d;
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
           rows[r] = rbase + (r & 3) + 8 * (r >> 2);
           v[r] = acc[i][j][r];
         }
-        if (p.splitk > 1) {
+        if (p.to_ws) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (rows[r] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[r]) * p.N + col] = v[r];
@@ -356,44 +359,91 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   }
 }
 
-// Split-K reduction + epilogue.  blockDim = (64 lanes over 4-element chunks, 4 split phases):
-// each thread sums every 4th slab for its 4 consecutive outputs, the 4 phases meet in LDS.
-template <bool VEC4>
+// Split-K reduction + epilogue.  blockDim 256 = (256/PH lanes over 4-element chunks) x (PH split
+// phases): each thread sums every PH-th slab for its 4 consecutive outputs, the phases meet in LDS
+// in a fixed order (deterministic).  PH = 16 keeps the grid large when M*N is small (batch-32 regime).
+// INTERP: the slabs hold the pre-activations of [real; fake] (M = 2R rows); every thread sums both
+// rows b and R+b and also emits row 2R+b = r + alpha[b]*(f - r): the first Dense layer is linear,
+// so this equals the layer applied to the interpolated input real + alpha*(fake - real)
+// (tf_utils.py:162-167) without a third pass over the weights.
+template <bool VEC4, int PH, bool INTERP>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const KParams p) {
-  __shared__ float4 red[3][64];
+  constexpr int LANES = 256 / PH;
+  constexpr int NV = INTERP ? 2 : 1;
+  __shared__ float4 red[NV][PH][LANES];
+  const int rows_out = INTERP ? p.interp_rows : p.M;
   const size_t mn = (size_t)p.M * p.N;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const size_t idx = ((size_t)blockIdx.x * 64 + tx) * 4;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (idx < mn) {
-    for (int s = ty; s < p.splitk; s += 4) {
-      const float *src = p.ws + (size_t)s * mn + idx;
-      if (VEC4) {
-        const float4 v = *reinterpret_cast<const float4 *>(src);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-      } else {
-        a.x += src[0];
-        if (idx + 1 < mn) a.y += src[1];
-        if (idx + 2 < mn) a.z += src[2];
-        if (idx + 3 < mn) a.w += src[3];
+  const size_t mn_out = (size_t)rows_out * p.N;
+  const int tx = threadIdx.x % LANES, ty = threadIdx.x / LANES;
+  const size_t idx = ((size_t)blockIdx.x * LANES + tx) * 4;
+  float4 a[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) a[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < mn_out) {
+    for (int s = ty; s < p.splitk; s += PH) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float *src = p.ws + (size_t)s * mn + (size_t)v * mn_out + idx;
+        if (VEC4) {
+          const float4 q = *reinterpret_cast<const float4 *>(src);
+          a[v].x += q.x; a[v].y += q.y; a[v].z += q.z; a[v].w += q.w;
+        } else {
+          a[v].x += src[0];
+          if (idx + 1 < mn_out) a[v].y += src[1];
+          if (idx + 2 < mn_out) a[v].z += src[2];
+          if (idx + 3 < mn_out) a[v].w += src[3];
+        }
       }
     }
   }
-  if (ty > 0) red[ty - 1][tx] = a;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) red[v][ty][tx] = a[v];
   __syncthreads();
-  if (ty == 0 && idx < mn) {
+  if (ty == 0 && idx < mn_out) {
+    float vals[NV][4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float4 v = red[k][tx];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (int v = 0; v < NV; ++v) {
+      float4 t = red[v][0][tx];
+#pragma unroll
+      for (int k = 1; k < PH; ++k) {
+        const float4 q = red[v][k][tx];
+        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+      }
+      vals[v][0] = t.x; vals[v][1] = t.y; vals[v][2] = t.z; vals[v][3] = t.w;
     }
-    const float vals[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (idx + e < mn) epilogue_store(p, (int)((idx + e) / p.N), (int)((idx + e) % p.N), vals[e]);
+    for (int e = 0; e < 4; ++e) {
+      if (idx + e >= mn_out) break;
+      const int row = (int)((idx + e) / p.N), col = (int)((idx + e) % p.N);
+      if (INTERP) {
+        const float r = vals[0][e], f = vals[NV - 1][e];
+        const float diff = f - r;
+        const float it = r + p.interp_alpha[row] * diff;
+        epilogue_store(p, row, col, r);
+        epilogue_store(p, rows_out + row, col, f);
+        epilogue_store(p, 2 * rows_out + row, col, it);
+      } else {
+        epilogue_store(p, row, col, vals[0][e]);
+      }
+    }
   }
 }
 
+template <bool INTERP>
+int launch_reduce(hipStream_t st, const KParams &p) {
+  const int64_t mn_out = (int64_t)(INTERP ? p.interp_rows : p.M) * p.N;
+  const bool vec = (mn_out % 4 == 0) && agx::aligned16(p.ws) && (((int64_t)p.M * p.N) % 4 == 0);
+  // small outputs: 16 phases x 16 lanes (64 outputs per block) keeps >= a few hundred blocks in flight
+  const bool many_phases = mn_out <= (int64_t)1 << 17 && p.splitk >= 8;
+  const int per_block = many_phases ? 64 : 256;
+  const int blocks = (int)agx::cdiv64(mn_out, per_block);
+#define AGX_RED(V, P) hipLaunchKernelGGL((splitk_reduce_kernel<V, P, INTERP>), dim3(blocks), dim3(256), 0, st, p)
+  if (many_phases) { if (vec) AGX_RED(true, 16); else AGX_RED(false, 16); }
+  else             { if (vec) AGX_RED(true, 4);  else AGX_RED(false, 4); }
+#undef AGX_RED
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
 
 // ---------------------------------------------------------------------------
 // Latency-oriented kernel for skinny / small products (batch 32 regime and the hidden layers):
@@ -477,7 +527,7 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
       rows[q] = m0 + rr;
       v[q] = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc];
     }
-    if (p.splitk > 1) {
+    if (p.to_ws) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (rows[q] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[q]) * p.N + col] = v[q];
@@ -669,6 +719,20 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
                       g->ws ? g->ws_floats : 0);
   p.splitk = pl.splitk;
   p.kchunk = pl.kchunk;
+  p.to_ws = pl.splitk > 1;
+  if (g->interp_rows > 0) {
+    // [real; fake] -> [real; fake; interpolated]: always finished by the reduce kernel
+    AGX_CHECK_ARG(g->M == 2 * g->interp_rows && g->interp_alpha, "agx_gemm_f32: interp needs M == 2*interp_rows and alpha");
+    AGX_CHECK_ARG(!g->rowsq && !g->rowscale && !g->mask && !g->accumulate && !g->addrow,
+                  "agx_gemm_f32: interp combines only with alpha/bias/act");
+    if (!g->ws || g->ws_floats < (int64_t)g->M * g->N) {
+      agx::set_error("agx_gemm_f32: interp needs a workspace of at least M*N floats");
+      return AGX_E_WORKSPACE;
+    }
+    p.interp_rows = g->interp_rows;
+    p.interp_alpha = g->interp_alpha;
+    p.to_ws = 1;
+  }
   const bool vec = agx::aligned16(g->A) && agx::aligned16(g->B) && (g->lda % 4 == 0) && (g->ldb % 4 == 0);
   hipStream_t st = agx::as_stream(stream);
   agx::ProfScope prof(st, g->prof_tagged ? g->prof_id : AGX_K_GEMM_UNTAGGED,
@@ -694,15 +758,8 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
     else rc = launch_direct<true, false>(st, p, pl.tiles, vec, gpw);
   }
   if (rc != AGX_OK) return rc;
-  if (p.splitk > 1) {
-    const int64_t mn = (int64_t)p.M * p.N;
-    const int blocks = (int)agx::cdiv64(mn, 256);
-    if (mn % 4 == 0 && agx::aligned16(p.ws))
-      hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, p);
-    else
-      hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, p);
-    AGX_LAUNCH_CHECK();
-  }
+  if (p.interp_rows > 0) return launch_reduce<true>(st, p);
+  if (p.to_ws) return launch_reduce<false>(st, p);
   return AGX_OK;
 }
 

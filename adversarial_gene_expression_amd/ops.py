@@ -11,7 +11,8 @@ from ._dev import ptr
 
 
 def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0, slope=0.0, mask=None,
-         out=None, accumulate=False, rowscale=None, rowsq=None, force_cfg=-1, force_splitk=0, use_ws=True):
+         out=None, accumulate=False, rowscale=None, rowsq=None, force_cfg=-1, force_splitk=0, use_ws=True,
+         interp=None):
     """out[M, N] = epilogue(alpha * op(A) @ op(B)); leading dimensions are the row strides."""
     lib = _lib.load()
     if out is None:
@@ -34,10 +35,13 @@ def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0,
         g.rowsq, g.rowsq_ld = ptr(rowsq), rowsq.stride(0)
     ws = None
     if use_ws:
-        wsf = max(int(lib.agx_gemm_ws_floats(M, N, K)), (force_splitk if force_splitk > 0 else 0) * M * N)
+        wsf = max(int(lib.agx_gemm_ws_floats(M, N, K)), (force_splitk if force_splitk > 0 else 0) * M * N,
+                  M * N if interp is not None else 0)
         ws = _dev.empty(max(wsf, 1))
         g.ws, g.ws_floats = ptr(ws), wsf
     g.force_cfg, g.force_splitk = force_cfg, force_splitk
+    if interp is not None:   # (rows, alpha): A = [real; fake], out gets the interpolated block too
+        g.interp_rows, g.interp_alpha = interp[0], ptr(interp[1])
     _lib.check(lib.agx_gemm_f32(_dev.stream(), g), 'agx_gemm_f32')
     return out
 

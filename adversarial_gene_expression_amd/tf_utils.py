@@ -460,7 +460,7 @@ tfk.optimizers = SimpleNamespace(RMSprop=RMSprop, Adam=Adam)
 class _Pair:
     """C-side step context of one (generator, critic) pair: descriptor + workspace."""
 
-    def __init__(self, gen, disc, max_batch):
+    def __init__(self, gen, disc, max_batch, max_steps=6):
         lib = _lib.load()
         if gen.x_dim != disc.x_dim or gen.vocab_sizes != disc.vocab_sizes or gen.nb_numeric != disc.nb_numeric:
             raise ValueError('generator and critic were built for different data / covariates')
@@ -471,7 +471,8 @@ class _Pair:
         cfg.gen, cfg.disc = gen.desc, disc.desc
         cfg.slope = gen.slope
         cfg.max_batch = max_batch
-        self.max_batch = max_batch
+        cfg.max_steps = max_steps
+        self.max_batch, self.max_steps = max_batch, max_steps
         self.handle = _lib.C.c_void_p()
         _lib.check(lib.agx_cgan_create(cfg, _lib.C.byref(self.handle)), 'agx_cgan_create')
         nbytes = int(lib.agx_cgan_workspace_bytes(self.handle))
@@ -531,11 +532,13 @@ class _Pair:
             pass
 
 
-def _pair(gen, disc, batch):
+def _pair(gen, disc, batch, steps=6):
     p = gen._pair.get(id(disc))
-    if p is None or p.max_batch < batch:
+    if p is None or p.max_batch < batch or p.max_steps < steps:
         _dev.device()
-        p = gen._pair[id(disc)] = _Pair(gen, disc, max(batch, 32))
+        if p is not None:
+            batch, steps = max(batch, p.max_batch), max(steps, p.max_steps)
+        p = gen._pair[id(disc)] = _Pair(gen, disc, max(batch, 32), max(steps, 6))
     return p
 
 
@@ -670,7 +673,7 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
     B = x.shape[0]
     if not _graph_ok(gen_opt, disc_opt, _world()[0]):
         raise ValueError('train_iteration needs one GPU and RMSprop on both networks')
-    pair = _pair(gen, disc, B)
+    pair = _pair(gen, disc, B, nb_critic + 1)
     aug_d = aug_g = None
     if p_aug:   # same per-trace constants, drawn in the order the reference's first calls would (:202-210, :240-247)
         aug_d = _aug_constants('disc', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)

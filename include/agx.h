@@ -98,6 +98,10 @@ typedef struct agx_gemm {
   int32_t force_splitk; /* <=0 auto                                              */
   int32_t prof_id;      /* AGX_K_* class for agx_prof_*; 0 with untagged = AGX_K_GEMM_UNTAGGED when prof_tagged == 0 */
   int32_t prof_tagged;  /* 1 if prof_id is meaningful                            */
+  int32_t interp_rows;  /* R > 0 (then M == 2R, C has 3R rows): A = [real; fake]; C rows  */
+  const float *interp_alpha; /* [0,2R) as usual and C[2R+b] = epilogue(r_b + alpha[b]*(f_b - r_b)):  */
+                        /* the Dense layer applied to real + alpha*(fake-real) (tf_utils.py:162-167) */
+                        /* by linearity, without a third pass over B.  Needs ws >= M*N floats. */
 } agx_gemm_t;
 int agx_gemm_f32(void *stream, const agx_gemm_t *p);
 /* Upper bound on the split-K scratch (floats) the heuristic may ask for. */
@@ -125,6 +129,15 @@ int agx_embed_bwd(void *stream, const agx_embed_t *e, float *grad_tables,
                   const float *dout, int32_t ldd, int32_t col0,
                   const int32_t *cat, int32_t ld_cat, int32_t B, int32_t row_mod,
                   int32_t accumulate);
+
+/* Stacked critic input (tf_utils.py:131 concat + :209-210/:247 augmentation) in one launch:
+ *   X[dst_row0 + b, 0:G]       = src[b, 0:G] (+ aug_mask[b] * aug_noise[b * aug_ldn + g])   b < src_rows, if src
+ *   X[r, G : G+n_num+E]        = [ num[r % B] | emb_0[cat[r % B, 0]] | ... ]                r < rows_cov
+ * (also builds the generator's layer-1 input [z | num | emb] for several stacked z batches: G = z_dim) */
+int agx_stack_rows(void *stream, const agx_embed_t *e, const float *tables, const float *src,
+                   int32_t lds, int32_t dst_row0, int32_t src_rows, const float *num, int32_t n_num, int32_t ld_num,
+                   const int32_t *cat, int32_t ld_cat, int32_t B, int32_t rows_cov, int32_t G, float *X,
+                   int32_t ldx, const float *aug_mask, const float *aug_noise, int32_t aug_ldn);
 
 /* ---- elementwise / reductions of the WGAN-GP loss: tf_utils.py:140-181 -- */
 /* inter = real + alpha[b] * (fake - real)            (tf_utils.py:162-164) */
@@ -170,6 +183,35 @@ int agx_colsum_weighted(void *stream, const float *A, int32_t lda, int32_t R, in
                         int32_t n0, int32_t n1, float c0, float c1, float c2, float *out,
                         float *bias_out);
 
+/* Every small gradient piece of one step in ONE launch (same arithmetic and summation order as
+ * agx_colsum / agx_colsum_weighted / agx_wgan_loss; the embedding job replaces the
+ * (delta . W_cov^T) product + agx_embed_bwd pair):
+ *   cs_*   : n_colsum BiasAddGrad jobs  out[j] = sum_{r0<=r<r1} A[r,j]
+ *   w_*    : Dense(1) gradient          out[j] = sum_r c(r) A[r,j], bias_out = n0*c0 + n1*c1  (w_A NULL: skip)
+ *   emb_*  : dE_i[v,d] = (sum_{r<emb_rows: cat[r % emb_B, i]==v} D[r,:]) . W[emb_col0+off_i+d, :]
+ *            (W = first-layer kernel [in,out], so the row is contiguous)               (emb_grad NULL: skip)
+ *   l_*    : loss scalars as agx_wgan_loss                                             (l_losses NULL: skip) */
+typedef struct agx_small_grads {
+  int32_t n_colsum;
+  const float *cs_A[AGX_MAX_LAYERS];
+  int32_t cs_lda[AGX_MAX_LAYERS], cs_r0[AGX_MAX_LAYERS], cs_r1[AGX_MAX_LAYERS], cs_H[AGX_MAX_LAYERS];
+  float *cs_out[AGX_MAX_LAYERS];
+  const float *w_A;
+  int32_t w_lda, w_R, w_H, w_n0, w_n1;
+  float w_c0, w_c1, w_c2;
+  float *w_out, *w_bias_out;
+  float *emb_grad;
+  agx_embed_t emb;
+  const float *emb_D, *emb_W;
+  const int32_t *emb_cat;
+  int32_t emb_ldd, emb_H, emb_ldw, emb_col0, emb_ld_cat, emb_B, emb_rows;
+  float *l_losses;
+  const float *l_out, *l_slopes;
+  int32_t l_n0, l_n1, l_ns;
+  float l_inv_b, l_gp_weight, l_fake_sign;
+} agx_small_grads_t;
+int agx_small_grads(void *stream, const agx_small_grads_t *jobs);
+
 /* ---- optimizers: tf_utils.py:221, 256, 285-288 (Keras-v2 semantics) ---- */
 /* rms = rho*rms + (1-rho) g^2 ; w -= lr * g / (sqrt(rms) + eps) */
 int agx_opt_rmsprop(void *stream, float *w, const float *g, float *rms, int64_t n, float lr,
@@ -188,6 +230,17 @@ int agx_rng_uniform(void *stream, float *out, int64_t n, uint64_t seed, uint64_t
 int agx_rng_at(void *stream, float *out, int64_t n, uint64_t seed, const uint64_t *base_dev,
                uint64_t sub_offset, int32_t normal);
 int agx_set_u64(void *stream, uint64_t *dst, uint64_t value);
+/* Several segments of those streams in ONE launch (all the z / alpha draws of a loop iteration,
+ * tf_utils.py:316-322): segment i fills out[0..n) from position *base_dev + sub_offset. */
+#define AGX_MAX_RNG_SEGS 16
+typedef struct agx_rng_seg {
+  float *out;
+  int64_t n;
+  uint64_t sub_offset;
+  int32_t normal; /* 1: N(0,1), 0: U[0,1) */
+} agx_rng_seg_t;
+int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_dev, int32_t n_seg,
+                  const agx_rng_seg_t *segs_host);
 
 /* ---- correlation path: utils.py:260-268, 808-873 ------------------------ */
 /* per-column mean and population std (ddof=0) of x[N,G]; sums in fp64.
@@ -237,6 +290,8 @@ typedef struct agx_cgan_config {
   agx_mlp_desc_t gen, disc;
   float slope;                      /* 0 = ReLU (reference)                     */
   int32_t max_batch;
+  int32_t max_steps;                /* nb_critic + 1 of the captured iteration (agx_cgan_iter_*): the generator */
+                                    /* runs ONCE per iteration on max_steps stacked z batches; 0 = 6          */
 } agx_cgan_config_t;
 
 typedef struct agx_cgan agx_cgan_t; /* opaque; host memory only */

@@ -161,3 +161,22 @@ def test_gemm_rowscale_and_row_sum_of_squares(gpu, M, N, K, cfg):
     sq2 = _dev.zeros((M, nslab + 2))
     ops.gemm(_dev_mat(A), _dev_mat(B), M, N, K, tb=1, rowscale=sd, rowsq=sq2, force_cfg=cfg)
     assert torch.equal(sq, sq2)   # fixed summation order
+
+
+@pytest.mark.parametrize('cfg,sk', [(-1, 0), (3, 1), (3, 7), (1, 3), (0, 1)])
+@pytest.mark.parametrize('R,N,K', [(5, 37, 16), (32, 256, 1100), (33, 130, 65)])
+def test_gemm_interpolated_rows_by_linearity(gpu, R, N, K, cfg, sk):
+    """A = [real; fake] (2R rows); C gets 3R rows: the third block is the layer applied to
+    real + alpha*(fake - real) (tf_utils.py:162-167), computed as r + alpha*(f - r) of the products."""
+    from adversarial_gene_expression_amd import ops, _dev
+    rs = np.random.RandomState(R + K)
+    A = rs.randn(2 * R, K).astype(np.float32)
+    B = (rs.randn(K, N) / np.sqrt(K)).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    alpha = rs.rand(R).astype(np.float32)
+    out = _dev.zeros((3 * R, _dev.r4(N)))
+    ops.gemm(_dev_mat(A), _dev_mat(B), 2 * R, N, K, bias=_dev.to_dev(bias), act=1, slope=0.0, out=out,
+             interp=(R, _dev.to_dev(alpha)), force_cfg=cfg, force_splitk=sk)
+    inter = A[:R] + alpha[:, None] * (A[R:] - A[:R])
+    full = np.concatenate([A, inter]).astype(np.float64) @ B.astype(np.float64) + bias
+    np.testing.assert_allclose(out.cpu().numpy()[:, :N], np.maximum(full, 0), atol=2e-5)

@@ -233,3 +233,109 @@ def test_critic_head_and_gp_finalize(gpu):
     np.testing.assert_allclose(d1d.cpu().numpy(), d1 * f[:, None], rtol=2e-5, atol=1e-7)
     got = xcd.cpu().numpy()
     assert np.all(got[:, 3:3 + ncov] == 0) and np.array_equal(got[:, :3], xc[:, :3]) and np.array_equal(got[:, 10:], xc[:, 10:])
+
+
+def test_rng_multi_matches_single_segment_streams(gpu):
+    """All draws of an iteration in one launch == the per-call streams at the same positions."""
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd import ops
+    from adversarial_gene_expression_amd._dev import ptr
+    base = _dev.zeros(2, dtype=torch.int64)
+    _lib.check(lib.agx_set_u64(_dev.stream(), ptr(base), 40))
+    spec = [(37 * 6, 0, 1), (37, 224, 0), (5, 264, 1), (1027, 272, 0)]
+    outs = [_dev.empty(n) for n, _, _ in spec]
+    segs = (_lib.RngSeg * len(spec))()
+    for s, o, (n, sub, normal) in zip(segs, outs, spec):
+        s.out, s.n, s.sub_offset, s.normal = ptr(o), n, sub, normal
+    _lib.check(lib.agx_rng_multi(_dev.stream(), 99, ptr(base), len(spec), segs))
+    for o, (n, sub, normal) in zip(outs, spec):
+        np.testing.assert_array_equal(o.cpu().numpy(), ops.rng(n, 99, 40 + sub, bool(normal)).cpu().numpy())
+
+
+@pytest.mark.parametrize('aug', [False, True])
+def test_stack_rows(gpu, aug):
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    rs = np.random.RandomState(3)
+    vocab, edim = [6, 3], [3, 2]
+    offs = [0, 64]
+    tables = rs.randn(128).astype(np.float32)
+    B, G, n_num = 5, 37, 2
+    ncov = n_num + sum(edim)
+    ldx = 48
+    src = rs.randn(B, 40).astype(np.float32)
+    num = rs.randn(B, n_num).astype(np.float32)
+    cat = np.stack([rs.randint(0, v, B) for v in vocab], 1).astype(np.int32)
+    mask = rs.binomial(1, 0.5, B).astype(np.float32)
+    noise = rs.randn(G).astype(np.float32)
+    X0 = rs.randn(3 * B, ldx).astype(np.float32)
+    X = _dev.to_dev(X0)
+    e = _embed_desc(_lib, vocab, edim, offs)
+    md, nz = (_dev.to_dev(mask), _dev.to_dev(noise)) if aug else (None, None)
+    td, sd, nd, cd = _dev.to_dev(tables), _dev.to_dev(src), _dev.to_dev(num), _dev.to_dev(cat, torch.int32)
+    _lib.check(lib.agx_stack_rows(_dev.stream(), e, ptr(td), ptr(sd), 40, B, B, ptr(nd), n_num, n_num, ptr(cd), 2, B,
+                                  2 * B, G, ptr(X), ldx, ptr(md), ptr(nz), 0))
+    want = X0.copy()
+    want[B:2 * B, :G] = src[:, :G] + (mask[:, None] * noise[None, :] if aug else 0)
+    rows = np.arange(2 * B) % B
+    cov = np.concatenate([num[rows]] + [tables[o:o + v * d].reshape(v, d)[cat[rows, i]]
+                                        for i, (v, d, o) in enumerate(zip(vocab, edim, offs))], 1)
+    want[:2 * B, G:G + ncov] = cov
+    np.testing.assert_array_equal(X.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('B,H', [(5, 48), (70, 256), (33, 600)])
+def test_small_grads_matches_separate_entry_points(gpu, B, H):
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    rs = np.random.RandomState(B)
+    R = 3 * B
+    vocab, edim, offs = [6, 3], [3, 2], [0, 64]
+    e = _embed_desc(_lib, vocab, edim, offs)
+    col0, nin = 11, 11 + sum(edim)
+    D1 = rs.randn(R, H).astype(np.float32)
+    D2 = rs.randn(R, 40).astype(np.float32)
+    AL = rs.randn(R, 40).astype(np.float32)
+    W = rs.randn(nin, H).astype(np.float32)
+    cat = np.stack([rs.randint(0, v, B) for v in vocab], 1).astype(np.int32)
+    out = rs.randn(R).astype(np.float32)
+    slopes = (1 + 0.3 * rs.randn(B)).astype(np.float32)
+    d = {k: _dev.to_dev(v) for k, v in dict(D1=D1, D2=D2, AL=AL, W=W, out=out, slopes=slopes).items()}
+    catd = _dev.to_dev(cat, torch.int32)
+    db1, db2, dw, dbo = _dev.empty(H), _dev.empty(40), _dev.empty(40), _dev.empty(1)
+    grad = _dev.to_dev(np.full(128, 7.0, np.float32))
+    losses = _dev.empty(4)
+    inv = 1.0 / B
+    j = _lib.SmallGrads()
+    j.n_colsum = 2
+    j.cs_A[0], j.cs_lda[0], j.cs_r0[0], j.cs_r1[0], j.cs_H[0], j.cs_out[0] = ptr(d['D1']), H, 0, 2 * B, H, ptr(db1)
+    j.cs_A[1], j.cs_lda[1], j.cs_r0[1], j.cs_r1[1], j.cs_H[1], j.cs_out[1] = ptr(d['D2']), 40, 0, 2 * B, 40, ptr(db2)
+    j.w_A, j.w_lda, j.w_R, j.w_H, j.w_n0, j.w_n1 = ptr(d['AL']), 40, R, 40, B, B
+    j.w_c0, j.w_c1, j.w_c2 = -inv, inv, 1.0
+    j.w_out, j.w_bias_out = ptr(dw), ptr(dbo)
+    j.emb_grad, j.emb = ptr(grad), e
+    j.emb_D, j.emb_W, j.emb_cat = ptr(d['D1']), ptr(d['W']), ptr(catd)
+    j.emb_ldd, j.emb_H, j.emb_ldw, j.emb_col0, j.emb_ld_cat, j.emb_B, j.emb_rows = H, H, H, col0, 2, B, 2 * B
+    j.l_losses, j.l_out, j.l_slopes = ptr(losses), ptr(d['out']), ptr(d['slopes'])
+    j.l_n0, j.l_n1, j.l_ns = B, B, B
+    j.l_inv_b, j.l_gp_weight, j.l_fake_sign = inv, 10.0, 1.0
+    _lib.check(lib.agx_small_grads(_dev.stream(), j))
+    np.testing.assert_allclose(db1.cpu().numpy(), D1[:2 * B].astype(np.float64).sum(0), atol=2e-5)
+    np.testing.assert_allclose(db2.cpu().numpy(), D2[:2 * B].astype(np.float64).sum(0), atol=2e-5)
+    c = np.concatenate([np.full(B, -inv), np.full(B, inv), np.ones(B)])
+    np.testing.assert_allclose(dw.cpu().numpy(), (c[:, None] * AL.astype(np.float64)).sum(0), atol=2e-5)
+    assert abs(float(dbo.cpu().numpy()[0])) < 1e-6
+    g = grad.cpu().numpy()
+    rows = np.arange(2 * B) % B
+    c0 = col0
+    for i, (v, dd, o) in enumerate(zip(vocab, edim, offs)):
+        dcov = D1[:2 * B].astype(np.float64) @ W[c0:c0 + dd].astype(np.float64).T
+        want = np.zeros((v, dd))
+        np.add.at(want, cat[rows, i], dcov)
+        np.testing.assert_allclose(g[o:o + v * dd].reshape(v, dd), want, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(want).max()))
+        c0 += dd
+    assert np.all(g[18:64] == 7.0)        # padding between tables untouched
+    ls = losses.cpu().numpy()
+    w = -out[:B].astype(np.float64).sum() * inv + out[B:2 * B].astype(np.float64).sum() * inv
+    gp = ((slopes.astype(np.float64) - 1) ** 2).sum() * inv
+    np.testing.assert_allclose(ls[:3], [w, gp, w + 10 * gp], rtol=1e-5, atol=1e-5)
