@@ -276,19 +276,30 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
       TileA::load(p.A, p.lda, m0, p.M, k0, kend, tid, ra);
       TileB::load(p.B, p.ldb, n0, p.N, k0, kend, tid, rb);
     }
+    // fragment reads run one k-pair ahead of the MFMAs that consume them (register double buffer):
+    // with one wave per SIMD nothing else hides the LDS latency between two MFMA groups
+    float fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = TileA::frag(cA, (wm * TM + i) * 32 + l31, lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = TileB::frag(cB, (wn * TN + j) * 32 + l31, lh);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = 2 * kk + lh;
-      float a[TM], b[TN];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 2) {
+        const int k = 2 * (kk + 1) + lh;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = TileA::frag(cA, (wm * TM + i) * 32 + l31, k);
+        for (int i = 0; i < TM; ++i) fa[nxt][i] = TileA::frag(cA, (wm * TM + i) * 32 + l31, k);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = TileB::frag(cB, (wn * TN + j) * 32 + l31, k);
+        for (int j = 0; j < TN; ++j) fb[nxt][j] = TileB::frag(cB, (wn * TN + j) * 32 + l31, k);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (hipcc sinks them otherwise)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
       float *nA = smem + ((t + 1) & 1) * STAGE;
@@ -482,6 +493,36 @@ __device__ __forceinline__ void frag_load4(const float *__restrict__ src, int ld
   for (int e = 0; e < 4; ++e) v[e] = (rv && k + e < kend) ? v[e] : 0.f;
 }
 
+// Interior fast path: `ub` is a wave-uniform base (scalar registers: tile origin + k of the group),
+// `lo` the lane's 32-bit element offset computed once per kernel, so a load costs no vector address
+// arithmetic (the clamped form above spends ~8 VALU instructions per dword on min / 64-bit mul-add,
+// more issue time than the MFMA it feeds).  No masking: callers use it only for full tiles / groups.
+template <bool KC, bool VEC>
+__device__ __forceinline__ void frag_fast4(const float *__restrict__ ub, int lo, int ld, float (&v)[4]) {
+  if (KC) {
+    if (VEC) {
+      const float4 q = *reinterpret_cast<const float4 *>(ub + lo);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      v[0] = ub[lo]; v[1] = ub[lo + 1]; v[2] = ub[lo + 2]; v[3] = ub[lo + 3];
+    }
+  } else {
+    v[0] = ub[lo];
+    v[1] = (ub + ld)[lo];
+    v[2] = (ub + 2 * (size_t)ld)[lo];
+    v[3] = (ub + 3 * (size_t)ld)[lo];
+  }
+}
+// uniform base of the 8-k group starting at absolute k for the 32-row slab starting at row r0
+template <bool KC>
+__device__ __forceinline__ const float *frag_ubase(const float *src, int ld, int r0, int k) {
+  return KC ? src + (size_t)r0 * ld + k : src + (size_t)k * ld + r0;
+}
+template <bool KC>
+__device__ __forceinline__ int frag_lane_off(int ld, int i, int h) {
+  return KC ? i * ld + 4 * h : 4 * h * ld + i;
+}
+
 template <bool TA, bool TB, bool VEC, int U>
 __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
   __shared__ float red[4][32][33];
@@ -500,7 +541,26 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
 
   // pass p covers groups [4U*p, 4U*(p+1)); wave w takes U consecutive ones, so that a wave's
   // loads of a k-contiguous row walk whole cache lines
-  for (int g0 = wave * U; g0 < ngroups; g0 += 4 * U) {
+  int g0 = wave * U;
+  if (m0 + 32 <= p.M && n0 + 32 <= p.N) {  // interior tile: full k-groups without clamps or masks
+    const int nfull = (kend - kbeg) / 8;
+    const int la = frag_lane_off<!TA>(p.lda, i, h), lb = frag_lane_off<TB>(p.ldb, i, h);
+    for (; g0 + U <= nfull; g0 += 4 * U) {
+      float av[U][4], bv[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = kbeg + 8 * (g0 + u);
+        frag_fast4<!TA, VEC>(frag_ubase<!TA>(p.A, p.lda, m0, k), la, p.lda, av[u]);
+        frag_fast4<TB, VEC>(frag_ubase<TB>(p.B, p.ldb, n0, k), lb, p.ldb, bv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
+    }
+  }
+  for (; g0 < ngroups; g0 += 4 * U) {
     float av[U][4], bv[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -544,6 +604,138 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Wave-granular kernel for products whose output is large and whose K is short (weight
+// gradients at batch 32: K = 3B = 96; wide outputs with K = H): ONE WAVE = one
+// (32 TM) x (32 TN) output tile over the whole K slice, MFMA fragments straight from global
+// memory / L2, no LDS, no barrier, register double buffering (the loads of the next U k-groups
+// are in flight while the MFMAs of the current ones issue).  Work is scheduled per wave, so
+// a grid of thousands of small independent tiles balances over the 1024 SIMDs where 128x128
+// workgroup tiles quantise badly (284 tiles on 256 CUs).
+// ---------------------------------------------------------------------------
+template <bool TA, bool TB, bool VEC, int TM, int TN, int U>
+__global__ void __launch_bounds__(64) gemm_wave_kernel(const KParams p) {
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int tiles_n = (p.N + 32 * TN - 1) / (32 * TN);
+  const int m0 = (blockIdx.x / tiles_n) * 32 * TM, n0 = (blockIdx.x % tiles_n) * 32 * TN;
+  const int z = blockIdx.y;
+  const int kbeg = z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int ngroups = (kend - kbeg + 7) / 8;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float av0[U][TM][4], bv0[U][TN][4], av1[U][TM][4], bv1[U][TN][4];
+#define AGX_WLOAD(AV, BV, G0)                                                              \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                          \
+    const int k = kbeg + 8 * ((G0) + u) + 4 * h;                                           \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a)                                         \
+        frag_load4<!TA, VEC>(p.A, p.lda, m0 + 32 * a + i, p.M, k, kend, AV[u][a]);         \
+    _Pragma("unroll") for (int b = 0; b < TN; ++b)                                         \
+        frag_load4<TB, VEC>(p.B, p.ldb, n0 + 32 * b + i, p.N, k, kend, BV[u][b]);          \
+  }
+#define AGX_WFAST(AV, BV, G0)                                                              \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                          \
+    const int k = kbeg + 8 * ((G0) + u);                                                   \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a)                                         \
+        frag_fast4<!TA, VEC>(frag_ubase<!TA>(p.A, p.lda, m0 + 32 * a, k), la, p.lda, AV[u][a]); \
+    _Pragma("unroll") for (int b = 0; b < TN; ++b)                                         \
+        frag_fast4<TB, VEC>(frag_ubase<TB>(p.B, p.ldb, n0 + 32 * b, k), lb, p.ldb, BV[u][b]);   \
+  }
+#define AGX_WMMA(AV, BV)                                                                   \
+  _Pragma("unroll") for (int u = 0; u < U; ++u)                                            \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                            \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a)                                           \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b)                                           \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[u][a][e], BV[u][b][e], acc[a][b], 0, 0, 0);
+  int gdone = 0;
+  if (m0 + 32 * TM <= p.M && n0 + 32 * TN <= p.N) {
+    // interior tile: batches of U full k-groups through the clamp-free loads
+    const int nfast = ((kend - kbeg) / 8 / U) * U;
+    const int la = frag_lane_off<!TA>(p.lda, i, h), lb = frag_lane_off<TB>(p.ldb, i, h);
+    if (nfast > 0) {
+      AGX_WFAST(av0, bv0, 0)
+      for (int g0 = 0; g0 < nfast; g0 += 2 * U) {
+        if (g0 + U < nfast) { AGX_WFAST(av1, bv1, g0 + U) }
+        AGX_WMMA(av0, bv0)
+        if (g0 + U < nfast) {
+          if (g0 + 2 * U < nfast) { AGX_WFAST(av0, bv0, g0 + 2 * U) }
+          AGX_WMMA(av1, bv1)
+        }
+      }
+    }
+    gdone = nfast;
+  }
+  for (int g0 = gdone; g0 < ngroups; g0 += U) {  // edge tiles and the K tail: clamped + masked loads
+    AGX_WLOAD(av0, bv0, g0)
+    AGX_WMMA(av0, bv0)
+  }
+#undef AGX_WLOAD
+#undef AGX_WFAST
+#undef AGX_WMMA
+
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + 32 * b + i;
+      const int rbase = m0 + 32 * a + 4 * h;
+      int rows[16];
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        rows[r] = rbase + (r & 3) + 8 * (r >> 2);
+        v[r] = acc[a][b][r];
+      }
+      if (p.to_ws) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rows[r] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[r]) * p.N + col] = v[r];
+      } else {
+        epilogue_column<16>(p, rows, col, v);
+        if (p.rowsq) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float q = v[r] * v[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            if (i == 0 && rows[r] < p.M && col < p.N) p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB, int TM, int TN>
+int launch_wave_t(hipStream_t st, const KParams &p, bool vec) {
+  const int tiles = agx::cdiv(p.M, 32 * TM) * agx::cdiv(p.N, 32 * TN);
+  dim3 grid(tiles, p.splitk, 1), block(64, 1, 1);
+  constexpr int U = (TM + TN <= 3) ? 4 : 2;
+  if (vec) hipLaunchKernelGGL((gemm_wave_kernel<TA, TB, true, TM, TN, U>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_wave_kernel<TA, TB, false, TM, TN, U>), grid, block, 0, st, p);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+template <bool TA, bool TB>
+int launch_wave(hipStream_t st, const KParams &p, bool vec, int tm, int tn) {
+  if (tm == 1 && tn == 1) return launch_wave_t<TA, TB, 1, 1>(st, p, vec);
+  if (tm == 1 && tn == 2) return launch_wave_t<TA, TB, 1, 2>(st, p, vec);
+  if (tm == 2 && tn == 1) return launch_wave_t<TA, TB, 2, 1>(st, p, vec);
+  if (tm == 2 && tn == 2) return launch_wave_t<TA, TB, 2, 2>(st, p, vec);
+  if (tm == 3 && tn == 1) return launch_wave_t<TA, TB, 3, 1>(st, p, vec);
+  if (tm == 1 && tn == 4) return launch_wave_t<TA, TB, 1, 4>(st, p, vec);
+  if (tm == 4 && tn == 1) return launch_wave_t<TA, TB, 4, 1>(st, p, vec);
+  return launch_wave_t<TA, TB, 3, 2>(st, p, vec);
 }
 
 template <bool TA, bool TB>
@@ -613,7 +805,10 @@ int launch_layout(hipStream_t st, const KParams &p, int tiles, int ta, int tb, b
 
 struct Plan {
   int cfg, bm, bn, tiles, splitk, kchunk;
+  int wtm, wtn;  // wave-kernel tile (cfg >= 8)
 };
+
+const int kWaveTiles[8][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {3, 1}, {1, 4}, {4, 1}, {3, 2}};
 
 Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_floats) {
   Plan pl;
@@ -624,23 +819,41 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
     const long long tilesL = (long long)agx::cdiv(M, 128) * agx::cdiv(N, 128);
     if (M <= 128 || ((long long)M * N <= (1 << 19) && K <= 2048))
       cfg = 3;  // skinny or small: latency-oriented direct kernel
-    else if (tilesL >= cus || (M > 64 && N > 64 && (long long)K * tilesL >= 40000))
+    else if (tilesL < 2 * cus && K <= 512 && (long long)agx::cdiv(M, 64) * agx::cdiv(N, 64) >= cus)
+      cfg = 1;  // short K, 128x128 tiles would leave a mostly empty second round: 4x as many 64x64 tiles
+    else if (tilesL >= cus || (M > 64 && N > 64 && (long long)K * tilesL >= 40000)) {
       cfg = 0;
+      // tile quantisation: 284 tiles on 256 CUs run as two rounds (55 % of the machine).  If the
+      // 64x64 tiling fills its rounds clearly better, take it (18161x256: 1136 tiles, 89 %).
+      const long long t64 = (long long)agx::cdiv(M, 64) * agx::cdiv(N, 64);
+      const double e128 = (double)tilesL / (double)(agx::cdiv64(tilesL, cus) * cus);
+      const double e64 = (double)t64 / (double)(agx::cdiv64(t64, cus) * cus);
+      if (tilesL >= cus && e128 < 0.8 && e64 > e128 + 0.12) cfg = 1;
+    }
     else
       cfg = 1;
   }
   pl.cfg = cfg;
+  pl.wtm = pl.wtn = 1;
   pl.bm = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : 32);
   pl.bn = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : (cfg == 2 ? 128 : 32));
+  if (cfg >= 8) {
+    pl.wtm = kWaveTiles[cfg - 8][0];
+    pl.wtn = kWaveTiles[cfg - 8][1];
+    pl.bm = 32 * pl.wtm;
+    pl.bn = 32 * pl.wtn;
+  }
   pl.tiles = agx::cdiv(M, pl.bm) * agx::cdiv(N, pl.bn);
   int sk = force_splitk;
   if (sk <= 0) {
     sk = 1;
-    if (cfg == 3) {
+    if (cfg >= 8) {
+      sk = 1;
+    } else if (cfg == 3) {
       // keep the per-block K range around 128..512 (1-2 load rounds per wave) while the grid
       // stays within a few waves of workgroups
       if (K > 512) {
-        sk = std::min(agx::cdiv(K, 128), agx::cdiv(4 * cus, pl.tiles));
+        sk = std::min(agx::cdiv(K, 128), agx::cdiv(2 * cus, pl.tiles));
         if (sk > agx::cdiv(K, 128)) sk = agx::cdiv(K, 128);
       }
     } else {
@@ -699,7 +912,7 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
   AGX_CHECK_ARG(g->ldc >= g->N, "agx_gemm_f32: ldc %d < N %d", g->ldc, g->N);
   AGX_CHECK_ARG(!g->addrow || (g->addmod > 0 && g->ldadd >= g->N), "agx_gemm_f32: bad addrow");
   AGX_CHECK_ARG(!g->mask || g->ldmask >= g->N, "agx_gemm_f32: bad mask ld");
-  AGX_CHECK_ARG(g->force_cfg <= 7, "agx_gemm_f32: force_cfg out of range");
+  AGX_CHECK_ARG(g->force_cfg <= 15, "agx_gemm_f32: force_cfg out of range");
 
   KParams p{};
   p.A = g->A; p.B = g->B; p.C = g->C;
@@ -751,7 +964,11 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
     rc = launch_layout<128, 128, 2, 2, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 7)
     rc = launch_layout<128, 128, 2, 4, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
-  else {
+  else if (pl.cfg >= 8) {
+    if (!g->ta && !g->tb) rc = launch_wave<false, false>(st, p, vec, pl.wtm, pl.wtn);
+    else if (!g->ta && g->tb) rc = launch_wave<false, true>(st, p, vec, pl.wtm, pl.wtn);
+    else rc = launch_wave<true, false>(st, p, vec, pl.wtm, pl.wtn);
+  } else {
     const int gpw = agx::cdiv(agx::cdiv(std::min(p.kchunk, p.K), 8), 4);  // 8-wide k groups per wave
     if (!g->ta && !g->tb) rc = launch_direct<false, false>(st, p, pl.tiles, vec, gpw);
     else if (!g->ta && g->tb) rc = launch_direct<false, true>(st, p, pl.tiles, vec, gpw);
