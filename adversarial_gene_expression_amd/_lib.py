@@ -99,11 +99,14 @@ class IterArgs(C.Structure):
         ('seed', C.c_uint64),
         ('aug_mask_disc', C.c_void_p), ('aug_noise_fake', C.c_void_p), ('aug_noise_real', C.c_void_p),
         ('aug_mask_gen', C.c_void_p), ('aug_noise_gen', C.c_void_p),
+        ('B_global', C.c_int32), ('row_lo', C.c_int32), ('split', C.c_int32),
+        ('disc_losses', C.c_void_p), ('gen_losses', C.c_void_p),
     ]
 
 
 class RngSeg(C.Structure):
-    _fields_ = [('out', C.c_void_p), ('n', C.c_int64), ('sub_offset', C.c_uint64), ('normal', C.c_int32)]
+    _fields_ = [('out', C.c_void_p), ('n', C.c_int64), ('sub_offset', C.c_uint64), ('normal', C.c_int32),
+                ('skip', C.c_int64)]
 
 
 class SmallGrads(C.Structure):
@@ -187,6 +190,9 @@ SIGNATURES = {
     'agx_cgan_gen_grads': (C.c_int, [_vp, _vp, C.POINTER(StepArgs)]),
     'agx_cgan_iter_capture': (C.c_int, [_vp, _vp, C.POINTER(IterArgs), C.POINTER(_vp)]),
     'agx_cgan_iter_launch': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _u64, _vp]),
+    'agx_cgan_iter_stage': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _u64]),
+    'agx_cgan_iter_num_segs': (_i32, [_vp]),
+    'agx_cgan_iter_launch_seg': (C.c_int, [_vp, _vp, _i32]),
     'agx_cgan_iter_rng_draws': (_i64, [_vp]),
     'agx_cgan_iter_destroy': (C.c_int, [_vp]),
 }

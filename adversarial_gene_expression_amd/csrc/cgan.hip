@@ -497,8 +497,9 @@ extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_ar
 // ---------------------------------------------------------------------------
 struct agx_iter_graph {
   agx_cgan *h = nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  int nseg = 0;
+  hipGraph_t graph[AGX_MAX_ITER_SEGS] = {};
+  hipGraphExec_t exec[AGX_MAX_ITER_SEGS] = {};
   int B = 0, nb_critic = 0;
   int64_t draws = 0;
 };
@@ -506,51 +507,71 @@ struct agx_iter_graph {
 namespace {
 inline uint64_t r4u(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
 
-int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int64_t *draws) {
+// Records segment `seg` of the iteration (seg < 0: the whole iteration).  Segments end where a
+// data-parallel run all-reduces a gradient buffer:
+//   0: draws, generator forward for all steps, critic gradients of step 0
+//   k (1..nbc-1): critic RMSprop, critic gradients of step k
+//   nbc: critic RMSprop, generator gradients          nbc+1: generator RMSprop
+// (nbc == 0: segment 0 holds the generator gradients).
+int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int seg, int64_t *draws) {
   const int B = a->B, Z = h->cfg.z_dim, nbc = a->nb_critic, S = nbc + 1, G = h->G;
+  const int Bg = a->B_global > 0 ? a->B_global : B, lo = a->row_lo;
   const agx_mlp_desc_t &dm = h->cfg.disc;
-  // every draw of the iteration in one launch (per 16 segments), at the stream positions the eager
-  // entry points use: z_k then alpha_k per critic step, then the generator step's z
-  agx_rng_seg_t segs[AGX_MAX_RNG_SEGS];
-  int ns = 0;
+  auto in_seg = [&](int s) { return seg < 0 || seg == s; };
   uint64_t sub = 0;
-  auto flush = [&]() -> int {
-    int rc = ns ? agx_rng_multi(st, a->seed, h->rngpos, ns, segs) : AGX_OK;
-    ns = 0;
-    return rc;
-  };
-  for (int k = 0; k <= nbc; ++k) {
-    if (ns + 2 > AGX_MAX_RNG_SEGS) AGX_TRY(flush());
-    segs[ns++] = agx_rng_seg_t{h->zbuf + (size_t)k * B * Z, (int64_t)B * Z, sub, 1};
-    sub += r4u((uint64_t)B * Z);
-    if (k < nbc) {
-      segs[ns++] = agx_rng_seg_t{h->abuf + (size_t)k * B, (int64_t)B, sub, 0};
-      sub += r4u((uint64_t)B);
+  {
+    // every draw of the iteration in one launch (per 16 segments), at the stream positions the eager
+    // entry points use for the GLOBAL batch (z_k then alpha_k per critic step, then the generator
+    // step's z); a rank keeps rows [lo, lo+B) of each draw
+    agx_rng_seg_t segs[AGX_MAX_RNG_SEGS];
+    int ns = 0;
+    auto flush = [&]() -> int {
+      int rc = (ns && in_seg(0)) ? agx_rng_multi(st, a->seed, h->rngpos, ns, segs) : AGX_OK;
+      ns = 0;
+      return rc;
+    };
+    for (int k = 0; k <= nbc; ++k) {
+      if (ns + 2 > AGX_MAX_RNG_SEGS) AGX_TRY(flush());
+      segs[ns++] = agx_rng_seg_t{h->zbuf + (size_t)k * B * Z, (int64_t)B * Z, sub, 1, (int64_t)lo * Z};
+      sub += r4u((uint64_t)Bg * Z);
+      if (k < nbc) {
+        segs[ns++] = agx_rng_seg_t{h->abuf + (size_t)k * B, (int64_t)B, sub, 0, (int64_t)lo};
+        sub += r4u((uint64_t)Bg);
+      }
     }
+    AGX_TRY(flush());
   }
-  AGX_TRY(flush());
-  // ONE generator forward for all nb_critic+1 z batches (generator weights are constant until the
-  // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
-  AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
-  AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx));
-  // real rows stay in X[0:B] for all critic steps (augmentation noise is a trace constant, :210)
-  AGX_HIP(hipMemcpy2DAsync(h->X, (size_t)h->ldx * 4, h->sx, (size_t)h->ldsx * 4, (size_t)G * 4, B,
-                           hipMemcpyDeviceToDevice, st));
-  if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, h->X, h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
-  for (int k = 0; k < nbc; ++k) {
-    // fake rows of this step (+ :209 noise row) into X[B:2B]; covariate columns from the CURRENT tables
-    AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)k * B * h->ldsx, h->ldsx, B, B, h->snum, dm.n_num,
-                           dm.n_num, h->scat, dm.emb.n_cat, B, 2 * B, G, h->X, h->ldx, a->aug_mask_disc,
-                           a->aug_noise_fake, 0));
-    AGX_TRY(critic_core(h, st, h->scat, B, B, h->abuf + (size_t)k * B, a->gp_weight, h->losslog + 4 * k));
-    AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
-  }
-  AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)nbc * B * h->ldsx, h->ldsx, 0, B, h->snum, dm.n_num,
-                         dm.n_num, h->scat, dm.emb.n_cat, B, B, G, h->X, h->ldx, a->aug_mask_gen,
-                         a->aug_noise_gen, G));
-  AGX_TRY(gen_core(h, st, h->scat, B, B, nbc * B, h->losslog + 4 * nbc));
-  AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
   *draws = (int64_t)sub;
+  if (in_seg(0)) {
+    // ONE generator forward for all nb_critic+1 z batches (generator weights are constant until the
+    // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
+    AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
+    AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx));
+    // real rows stay in X[0:B] for all critic steps (augmentation noise is a trace constant, :210)
+    AGX_HIP(hipMemcpy2DAsync(h->X, (size_t)h->ldx * 4, h->sx, (size_t)h->ldsx * 4, (size_t)G * 4, B,
+                             hipMemcpyDeviceToDevice, st));
+    if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, h->X, h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
+  }
+  for (int k = 0; k < nbc; ++k) {
+    if (in_seg(k)) {
+      // fake rows of this step (+ :209 noise row) into X[B:2B]; covariate columns from the CURRENT tables
+      AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)k * B * h->ldsx, h->ldsx, B, B, h->snum, dm.n_num,
+                             dm.n_num, h->scat, dm.emb.n_cat, B, 2 * B, G, h->X, h->ldx, a->aug_mask_disc,
+                             a->aug_noise_fake, 0));
+      AGX_TRY(critic_core(h, st, h->scat, B, Bg, h->abuf + (size_t)k * B, a->gp_weight,
+                          a->disc_losses ? a->disc_losses : h->losslog + 4 * k));
+    }
+    if (in_seg(k + 1))
+      AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
+  }
+  if (in_seg(nbc)) {
+    AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)nbc * B * h->ldsx, h->ldsx, 0, B, h->snum, dm.n_num,
+                           dm.n_num, h->scat, dm.emb.n_cat, B, B, G, h->X, h->ldx, a->aug_mask_gen,
+                           a->aug_noise_gen, G));
+    AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc));
+  }
+  if (in_seg(nbc + 1))
+    AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
   return AGX_OK;
 }
 }  // namespace
@@ -561,6 +582,10 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   if (!h->bound) { agx::set_error("agx_cgan_iter_capture: not bound"); return AGX_E_STATE; }
   AGX_CHECK_ARG(a->B > 0 && a->B <= h->Bm, "agx_cgan_iter_capture: batch %d outside (0, %d]", a->B, h->Bm);
   AGX_CHECK_ARG(a->nb_critic >= 0 && a->nb_critic < h->S, "agx_cgan_iter_capture: nb_critic %d needs max_steps > %d (have %d)", a->nb_critic, a->nb_critic, h->S);
+  AGX_CHECK_ARG(a->nb_critic + 2 <= AGX_MAX_ITER_SEGS, "agx_cgan_iter_capture: nb_critic %d too large", a->nb_critic);
+  AGX_CHECK_ARG(a->B_global == 0 || (a->B_global >= a->B && a->row_lo >= 0 && a->row_lo + a->B <= a->B_global),
+                "agx_cgan_iter_capture: rows [%d, %d) outside the global batch %d", a->row_lo, a->row_lo + a->B, a->B_global);
+  AGX_CHECK_ARG(a->B_global != 0 || a->row_lo == 0, "agx_cgan_iter_capture: row_lo without B_global");
   AGX_CHECK_ARG(a->disc_rms && a->gen_rms, "agx_cgan_iter_capture: optimizer slots missing");
   AGX_CHECK_ARG(!a->aug_mask_disc || (a->aug_noise_fake && a->aug_noise_real), "agx_cgan_iter_capture: critic aug noise missing");
   AGX_CHECK_ARG(!a->aug_mask_gen || a->aug_noise_gen, "agx_cgan_iter_capture: generator aug noise missing");
@@ -573,52 +598,68 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   agx_iter_graph *g = new (std::nothrow) agx_iter_graph();
   AGX_CHECK_ARG(g, "agx_cgan_iter_capture: out of host memory");
   g->h = h; g->B = a->B; g->nb_critic = a->nb_critic;
-  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
-  if (e != hipSuccess) {
-    delete g;
-    agx::set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
-    return AGX_E_HIP;
-  }
-  int rc = record_iteration(h, st, a, &g->draws);
-  e = hipStreamEndCapture(st, &g->graph);
-  if (rc != AGX_OK) {
-    if (g->graph) (void)hipGraphDestroy(g->graph);
-    delete g;
-    return rc;
-  }
-  if (e != hipSuccess || !g->graph) {
-    delete g;
-    agx::set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    return AGX_E_HIP;
-  }
-  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-  if (e != hipSuccess) {
-    (void)hipGraphDestroy(g->graph);
-    delete g;
-    agx::set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    return AGX_E_HIP;
+  const int nseg = a->split ? a->nb_critic + 2 : 1;
+  for (int s = 0; s < nseg; ++s) {
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+      agx_cgan_iter_destroy(g);
+      agx::set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+      return AGX_E_HIP;
+    }
+    int rc = record_iteration(h, st, a, a->split ? s : -1, &g->draws);
+    e = hipStreamEndCapture(st, &g->graph[s]);
+    g->nseg = s + 1;
+    if (rc != AGX_OK) {
+      agx_cgan_iter_destroy(g);
+      return rc;
+    }
+    if (e != hipSuccess || !g->graph[s]) {
+      agx_cgan_iter_destroy(g);
+      agx::set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      return AGX_E_HIP;
+    }
+    e = hipGraphInstantiate(&g->exec[s], g->graph[s], nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+      agx_cgan_iter_destroy(g);
+      agx::set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+      return AGX_E_HIP;
+    }
   }
   *out = g;
+  return AGX_OK;
+}
+
+extern "C" int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
+                                   const int32_t *cat, const float *num, uint64_t rng_offset) {
+  AGX_CHECK_ARG(g && g->nseg > 0 && x, "agx_cgan_iter_stage: null argument");
+  agx_cgan *h = g->h;
+  AGX_CHECK_ARG(ldx >= h->G, "agx_cgan_iter_stage: ldx < x_dim");
+  hipStream_t st = agx::as_stream(stream);
+  const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
+  AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_stage: covariates missing");
+  AGX_HIP(hipMemcpy2DAsync(h->sx, (size_t)h->ldsx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
+                           hipMemcpyDeviceToDevice, st));
+  if (ncat) AGX_HIP(hipMemcpyAsync(h->scat, cat, (size_t)B * ncat * 4, hipMemcpyDeviceToDevice, st));
+  if (nnum) AGX_HIP(hipMemcpyAsync(h->snum, num, (size_t)B * nnum * 4, hipMemcpyDeviceToDevice, st));
+  return agx_set_u64(st, h->rngpos, rng_offset);
+}
+
+extern "C" int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g) { return g ? g->nseg : 0; }
+
+extern "C" int agx_cgan_iter_launch_seg(agx_iter_graph_t *g, void *stream, int32_t seg) {
+  AGX_CHECK_ARG(g && seg >= 0 && seg < g->nseg && g->exec[seg], "agx_cgan_iter_launch_seg: bad segment");
+  AGX_HIP(hipGraphLaunch(g->exec[seg], agx::as_stream(stream)));
   return AGX_OK;
 }
 
 extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
                                     const int32_t *cat, const float *num, uint64_t rng_offset,
                                     float *losses_out) {
-  AGX_CHECK_ARG(g && g->exec && x, "agx_cgan_iter_launch: null argument");
-  agx_cgan *h = g->h;
-  AGX_CHECK_ARG(ldx >= h->G, "agx_cgan_iter_launch: ldx < x_dim");
+  AGX_TRY(agx_cgan_iter_stage(g, stream, x, ldx, cat, num, rng_offset));
   hipStream_t st = agx::as_stream(stream);
-  const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
-  AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_launch: covariates missing");
-  AGX_HIP(hipMemcpy2DAsync(h->sx, (size_t)h->ldsx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
-                           hipMemcpyDeviceToDevice, st));
-  if (ncat) AGX_HIP(hipMemcpyAsync(h->scat, cat, (size_t)B * ncat * 4, hipMemcpyDeviceToDevice, st));
-  if (nnum) AGX_HIP(hipMemcpyAsync(h->snum, num, (size_t)B * nnum * 4, hipMemcpyDeviceToDevice, st));
-  AGX_TRY(agx_set_u64(st, h->rngpos, rng_offset));
-  AGX_HIP(hipGraphLaunch(g->exec, st));
+  for (int s = 0; s < g->nseg; ++s) AGX_HIP(hipGraphLaunch(g->exec[s], st));
   if (losses_out)
-    AGX_HIP(hipMemcpyAsync(losses_out, h->losslog, (size_t)(g->nb_critic + 1) * 4 * sizeof(float),
+    AGX_HIP(hipMemcpyAsync(losses_out, g->h->losslog, (size_t)(g->nb_critic + 1) * 4 * sizeof(float),
                            hipMemcpyDeviceToDevice, st));
   return AGX_OK;
 }
@@ -627,8 +668,10 @@ extern "C" int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g) { return g
 
 extern "C" int agx_cgan_iter_destroy(agx_iter_graph_t *g) {
   if (g) {
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
+    for (int s = 0; s < AGX_MAX_ITER_SEGS; ++s) {
+      if (g->exec[s]) (void)hipGraphExecDestroy(g->exec[s]);
+      if (g->graph[s]) (void)hipGraphDestroy(g->graph[s]);
+    }
     delete g;
   }
   return AGX_OK;

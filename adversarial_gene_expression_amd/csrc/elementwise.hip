@@ -356,10 +356,12 @@ __global__ void set_u64_kernel(unsigned long long *dst, unsigned long long v) { 
 // elements 4q..4q+3 of the (seed, offset)-keyed stream; NORMAL: Box-Muller, else U[0,1)
 template <bool NORMAL>
 __device__ __forceinline__ void rng_fill(float *__restrict__ out, long long n, unsigned long long seed,
-                                         unsigned long long offset, long long q0, long long qstride) {
-  // counter block q produces elements 4q .. 4q+3 of the (seed, offset)-keyed stream
-  const long long nq = (n + 3) >> 2;
-  for (long long q = q0; q < nq; q += qstride) {
+                                         unsigned long long offset, long long q0, long long qstride,
+                                         long long skip = 0) {
+  // counter block q produces elements 4q .. 4q+3 of the (seed, offset)-keyed stream; out receives
+  // elements [skip, skip + n)
+  const long long qlo = skip >> 2, nq = (skip + n + 3) >> 2;
+  for (long long q = qlo + q0; q < nq; q += qstride) {
     const unsigned long long ctr = (offset >> 2) + (unsigned long long)q;
     unsigned r[4];
     philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)(offset & 3u), NORMAL ? 1u : 0u,
@@ -378,8 +380,10 @@ __device__ __forceinline__ void rng_fill(float *__restrict__ out, long long n, u
       v[0] = u01(r[0]); v[1] = u01(r[1]); v[2] = u01(r[2]); v[3] = u01(r[3]);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (4 * q + k < n) out[4 * q + k] = v[k];
+    for (int k = 0; k < 4; ++k) {
+      const long long j = 4 * q + k - skip;
+      if (j >= 0 && j < n) out[j] = v[k];
+    }
   }
 }
 
@@ -405,8 +409,8 @@ __global__ void __launch_bounds__(256) rng_multi_kernel(const RngSegs segs, unsi
   unsigned long long offset = sg.sub_offset + (base_dev ? *base_dev : 0ull);
   const long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long qs = (long long)gridDim.x * blockDim.x;
-  if (sg.normal) rng_fill<true>(sg.out, sg.n, seed, offset, q0, qs);
-  else rng_fill<false>(sg.out, sg.n, seed, offset, q0, qs);
+  if (sg.normal) rng_fill<true>(sg.out, sg.n, seed, offset, q0, qs, sg.skip);
+  else rng_fill<false>(sg.out, sg.n, seed, offset, q0, qs, sg.skip);
 }
 
 // ---------------------------------------------------------------------------
@@ -832,9 +836,10 @@ extern "C" int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_d
   rs.n = n_seg;
   long long nmax = 0;
   for (int i = 0; i < n_seg; ++i) {
-    AGX_CHECK_ARG(segs[i].out && segs[i].n >= 0, "agx_rng_multi: segment %d", i);
+    AGX_CHECK_ARG(segs[i].out && segs[i].n >= 0 && segs[i].skip >= 0 && (segs[i].sub_offset & 3) == 0,
+                  "agx_rng_multi: segment %d", i);
     rs.seg[i] = segs[i];
-    nmax = std::max<long long>(nmax, segs[i].n);
+    nmax = std::max<long long>(nmax, segs[i].n + 3);
   }
   for (int i = n_seg; i < AGX_MAX_RNG_SEGS; ++i) rs.seg[i] = segs[0];
   hipLaunchKernelGGL(rng_multi_kernel, dim3(grid_for((nmax + 3) / 4, 256, 256), n_seg), dim3(256), 0,

@@ -483,10 +483,13 @@ class _Pair:
         self._graphs = {}
         self._keep = {}
 
-    def iteration_graph(self, gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, aug_d=None, aug_g=None):
-        """Capture (once per key) the whole loop iteration of tf_utils.py:316-323 as a hipGraph."""
+    def iteration_graph(self, gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, aug_d=None, aug_g=None,
+                        batch_global=None, row_lo=0, split=False):
+        """Capture (once per key) the whole loop iteration of tf_utils.py:316-323 as a hipGraph
+        (split=True: one graph per segment between the gradient all-reduces of a data-parallel run)."""
+        Bg = int(batch_global) if batch_global else B
         key = (B, nb_critic, float(gp_weight), int(seed), id(gen_opt), id(disc_opt), gen_opt.learning_rate,
-               disc_opt.learning_rate, id(aug_d), id(aug_g))
+               disc_opt.learning_rate, id(aug_d), id(aug_g), Bg, int(row_lo), bool(split))
         g = self._graphs.get(key)
         if g is None:
             lib = _lib.load()
@@ -501,6 +504,11 @@ class _Pair:
                                                                        ptr(aug_d['noise_real']))
             if aug_g is not None:
                 a.aug_mask_gen, a.aug_noise_gen = ptr(aug_g['mask']), ptr(aug_g['noise'])
+            if split or Bg != B:
+                a.B_global, a.row_lo, a.split = Bg, int(row_lo), int(bool(split))
+                # loss scalars go to the slots behind the gradients, so they ride the all-reduce
+                a.disc_losses = disc.grads.data_ptr() + 4 * disc.n_flat
+                a.gen_losses = gen.grads.data_ptr() + 4 * gen.n_flat
             self._keep[key] = (aug_d, aug_g)
             g = _lib.C.c_void_p()
             side = torch.cuda.Stream()          # capture needs a non-default stream
@@ -557,7 +565,7 @@ def _allreduce_grads(net):
 _TRACE_CONSTS = {}
 
 
-def _aug_constants(tag, key, p_aug, norm_scale, bs, nb_genes):
+def _aug_constants(tag, key, p_aug, norm_scale, bs, nb_genes, rows=None):
     """The reference draws augmentation masks/noise with NumPy INSIDE ``@tf.function``
     (tf_utils.py:202, :209-210, :240, :247), so they are constants of each trace
     (one per input shape).  Same here: drawn once per (function, models, batch shape)
@@ -572,6 +580,9 @@ def _aug_constants(tag, key, p_aug, norm_scale, bs, nb_genes):
             c = {'mask': augs, 'noise_fake': nf, 'noise_real': nr}
         else:
             c = {'mask': augs, 'noise': np.random.normal(0, norm_scale, (bs, nb_genes))}
+        if rows is not None:   # data parallel: constants of the GLOBAL batch (same NumPy seed on every rank), own rows
+            lo, hi = rows
+            c = {n: (v if n == 'noise_fake' else v[lo:hi]) for n, v in c.items()}
         c = {n: _dev.to_dev(v) for n, v in c.items()}
         _TRACE_CONSTS[k] = c
     return c
@@ -653,39 +664,67 @@ def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None,
     return DeviceArray(gen.grads[gen.n_flat:gen.n_flat + 1].clone())
 
 
-def _graph_ok(gen_opt, disc_opt, world):
-    return (world == 1 and type(gen_opt) is RMSprop and type(disc_opt) is RMSprop
+def _graph_ok(gen_opt, disc_opt, world=1):
+    return (type(gen_opt) is RMSprop and type(disc_opt) is RMSprop
             and gen_opt.rho == disc_opt.rho and gen_opt.epsilon == disc_opt.epsilon)
 
 
 def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_penalty_weight=10, p_aug=0,
-                    norm_scale=0.5):
+                    norm_scale=0.5, *, batch_global=None, row_lo=0):
     """One iteration of the reference loop body (tf_utils.py:314-324) - ``nb_critic`` critic steps
-    with fresh z / alpha on the same real batch, then one generator step - replayed as ONE hipGraph.
-    Draws come from the module Philox stream at the same positions the eager ``train_disc`` /
-    ``train_gen`` calls would use.  Returns (last critic loss, generator loss) as DeviceArrays.
-    Single GPU, RMSprop on both nets (the reference defaults); ``train`` falls back to the eager
-    step functions otherwise."""
+    with fresh z / alpha on the same real batch, then one generator step - replayed as ONE hipGraph
+    (the generator runs once on all nb_critic+1 z batches: its weights are constant inside an
+    iteration).  Draws come from the module Philox stream at the same positions the eager
+    ``train_disc`` / ``train_gen`` calls would use.  Returns (last critic loss, generator loss).
+
+    Under torch.distributed (one process per GPU) ``x`` holds this rank's rows
+    ``[row_lo, row_lo + len(x))`` of a global batch of ``batch_global`` rows: the iteration is
+    captured as nb_critic+2 graph segments with one RCCL sum all-reduce of the flat gradient buffer
+    between them; draws are the global batch's, so R ranks reproduce the one-GPU big-batch run.
+    RMSprop on both nets (the reference defaults); ``train`` falls back to the eager step
+    functions otherwise."""
     lib = _lib.load()
     x = _dev.to_dev(x)
     cc = _dev.to_dev(cc, torch.int32)
     nc = _dev.to_dev(nc)
     B = x.shape[0]
-    if not _graph_ok(gen_opt, disc_opt, _world()[0]):
-        raise ValueError('train_iteration needs one GPU and RMSprop on both networks')
+    world, _ = _world()
+    if not _graph_ok(gen_opt, disc_opt):
+        raise ValueError('train_iteration needs RMSprop on both networks')
+    Bg = int(batch_global) if batch_global else B * world
+    if world == 1 and Bg != B:
+        raise ValueError('batch_global differs from the local batch on a single GPU')
     pair = _pair(gen, disc, B, nb_critic + 1)
     aug_d = aug_g = None
     if p_aug:   # same per-trace constants, drawn in the order the reference's first calls would (:202-210, :240-247)
-        aug_d = _aug_constants('disc', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
-        aug_g = _aug_constants('gen', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
-    g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, grad_penalty_weight, _rng.seed, aug_d, aug_g)
-    losses = _dev.empty((nb_critic + 1, 4))
-    _lib.check(lib.agx_cgan_iter_launch(g, _dev.stream(), ptr(x), x.stride(0), ptr(cc), ptr(nc), _rng.offset,
-                                        ptr(losses)), 'agx_cgan_iter_launch')
+        rows = (row_lo, row_lo + B) if world > 1 else None
+        aug_d = _aug_constants('disc', (id(gen), id(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
+        aug_g = _aug_constants('gen', (id(gen), id(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
+    g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, grad_penalty_weight, _rng.seed, aug_d, aug_g,
+                             batch_global=Bg, row_lo=row_lo, split=world > 1)
+    if world == 1:
+        losses = _dev.empty((nb_critic + 1, 4))
+        _lib.check(lib.agx_cgan_iter_launch(g, _dev.stream(), ptr(x), x.stride(0), ptr(cc), ptr(nc), _rng.offset,
+                                            ptr(losses)), 'agx_cgan_iter_launch')
+        d_loss = DeviceArray(losses[nb_critic - 1, 2:3]) if nb_critic > 0 else None
+        g_loss = DeviceArray(losses[nb_critic, 0:1])
+    else:
+        _lib.check(lib.agx_cgan_iter_stage(g, _dev.stream(), ptr(x), x.stride(0), ptr(cc), ptr(nc), _rng.offset),
+                   'agx_cgan_iter_stage')
+        d_loss = None
+        for s in range(nb_critic + 2):
+            _lib.check(lib.agx_cgan_iter_launch_seg(g, _dev.stream(), s), 'agx_cgan_iter_launch_seg')
+            if s < nb_critic:
+                _allreduce_grads(disc)
+                if s == nb_critic - 1:
+                    d_loss = DeviceArray(disc.grads[disc.n_flat + 2:disc.n_flat + 3].clone())
+            elif s == nb_critic:
+                _allreduce_grads(gen)
+        g_loss = DeviceArray(gen.grads[gen.n_flat:gen.n_flat + 1].clone())
     _rng.offset += int(lib.agx_cgan_iter_rng_draws(g))
     disc_opt.iterations += nb_critic
     gen_opt.iterations += 1
-    return (DeviceArray(losses[nb_critic - 1, 2:3]) if nb_critic > 0 else None), DeviceArray(losses[nb_critic, 0:1])
+    return d_loss, g_loss
 
 
 def _shard(lo, hi, world, rank):
@@ -737,8 +776,9 @@ def train(dataset, cat_covs, num_covs, z_dim, epochs, batch_size, gen, disc, sco
             if hi_r <= lo_r:
                 raise ValueError('global batch of %d rows cannot be split over %d ranks' % (bg, world))
             x, cc, nc = data[lo_r:hi_r], ccs[lo_r:hi_r], ncs[lo_r:hi_r]
-            if use_graph and noise_fn is None and nb_critic > 0 and _graph_ok(gen_opt, disc_opt, world):
-                d_l, g_l = train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, 10, p_aug, norm_scale)
+            if use_graph and noise_fn is None and nb_critic > 0 and _graph_ok(gen_opt, disc_opt):
+                d_l, g_l = train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, 10, p_aug, norm_scale,
+                                           batch_global=bg, row_lo=lo_r - i)
                 dl.append(d_l)
                 gl.append(g_l)
                 continue

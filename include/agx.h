@@ -236,8 +236,10 @@ int agx_set_u64(void *stream, uint64_t *dst, uint64_t value);
 typedef struct agx_rng_seg {
   float *out;
   int64_t n;
-  uint64_t sub_offset;
+  uint64_t sub_offset;  /* multiple of 4 */
   int32_t normal; /* 1: N(0,1), 0: U[0,1) */
+  int64_t skip;   /* out[j] = element skip + j of the stream at that position (a rank's rows */
+                  /* of a global-batch draw)                                                */
 } agx_rng_seg_t;
 int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_dev, int32_t n_seg,
                   const agx_rng_seg_t *segs_host);
@@ -344,7 +346,15 @@ typedef struct agx_iter_args {
   uint64_t seed;            /* Philox seed                                               */
   const float *aug_mask_disc, *aug_noise_fake, *aug_noise_real; /* NULL or trace constants */
   const float *aug_mask_gen, *aug_noise_gen;
+  /* data parallel (all 0 / NULL on one GPU): this rank holds rows [row_lo, row_lo+B) of a global  */
+  /* batch of B_global rows; draws are the global batch's, means divide by B_global; split = 1      */
+  /* captures one graph per segment between gradient all-reduces (agx_cgan_iter_launch_seg);        */
+  /* disc_losses / gen_losses (device [4]) redirect the loss scalars, e.g. into slots that ride the */
+  /* gradient all-reduce.                                                                           */
+  int32_t B_global, row_lo, split;
+  float *disc_losses, *gen_losses;
 } agx_iter_args_t;
+#define AGX_MAX_ITER_SEGS 66
 typedef struct agx_iter_graph agx_iter_graph_t;
 int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter_args_t *a,
                           agx_iter_graph_t **out);
@@ -354,6 +364,13 @@ int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter_args_t *a,
 int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
                          const int32_t *cat, const float *num, uint64_t rng_offset,
                          float *losses_out);
+/* Split form for data-parallel runs: stage once, then launch segments 0 .. num_segs-1 with a
+ * sum all-reduce of the critic (after segments 0..nb_critic-1) or generator (after segment
+ * nb_critic) gradient buffer in between (RCCL, issued by the caller on the same stream). */
+int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
+                        const int32_t *cat, const float *num, uint64_t rng_offset);
+int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g);
+int agx_cgan_iter_launch_seg(agx_iter_graph_t *g, void *stream, int32_t seg);
 int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g);
 int agx_cgan_iter_destroy(agx_iter_graph_t *g);
 

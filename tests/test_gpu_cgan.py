@@ -254,3 +254,90 @@ def test_graph_iteration_is_bit_identical_to_eager(gpu, p_aug):
     for a, b in zip(gw0 + dw0 + r0, gw1 + dw1 + r1):
         np.testing.assert_array_equal(a, b)
     assert tr0['gen_loss'] == tr1['gen_loss'] and tr0['disc_loss'] == tr1['disc_loss']
+
+
+def _iteration_by_segments(T, gens, discs, gopts, dopts, shards, Bg, nb_critic, seed, offset, p_aug=0):
+    """Drive the split (data-parallel) form of the captured iteration for several 'ranks' that live
+    on ONE GPU: every rank launches segment s, then the gradient buffers are summed across ranks
+    (what the RCCL all-reduce does) before the next segment."""
+    from adversarial_gene_expression_amd import _dev, _lib
+    from adversarial_gene_expression_amd._dev import ptr
+    lib = _lib.load()
+    graphs, keep = [], []
+    for r, (x, cc, nc, lo) in enumerate(shards):
+        xd, cd, nd = _dev.to_dev(x), _dev.to_dev(cc, torch.int32), _dev.to_dev(nc)
+        pair = T._pair(gens[r], discs[r], xd.shape[0], nb_critic + 1)
+        g = pair.iteration_graph(gens[r], discs[r], gopts[r], dopts[r], xd.shape[0], nb_critic, 10.0, seed,
+                                 batch_global=Bg, row_lo=lo, split=True)
+        assert lib.agx_cgan_iter_num_segs(g) == nb_critic + 2
+        _lib.check(lib.agx_cgan_iter_stage(g, _dev.stream(), ptr(xd), xd.stride(0), ptr(cd), ptr(nd), offset))
+        graphs.append(g)
+        keep.append((xd, cd, nd))
+    d_loss = g_loss = None
+    for s in range(nb_critic + 2):
+        for g in graphs:
+            _lib.check(lib.agx_cgan_iter_launch_seg(g, _dev.stream(), s))
+        nets = discs if s < nb_critic else (gens if s == nb_critic else [])
+        if nets:
+            total = torch.stack([n.grads for n in nets]).sum(0)
+            for n in nets:
+                n.grads.copy_(total)
+            if s == nb_critic - 1:
+                d_loss = float(discs[0].grads[discs[0].n_flat + 2])
+            if s == nb_critic:
+                g_loss = float(gens[0].grads[gens[0].n_flat])
+    torch.cuda.synchronize()
+    return d_loss, g_loss
+
+
+def test_split_iteration_equals_whole_graph(gpu):
+    """One rank, split into nb_critic+2 segments == the single-graph iteration, bit for bit."""
+    from adversarial_gene_expression_amd import tf_utils as T
+    p = make_problem(G=61, B=24, H=(24, 16), seed=11)
+    x, cc, nc = _f32(p, 'x'), p['cc'], _f32(p, 'nc')
+    _, g0, d0 = _models(p)
+    T.set_seed(77)
+    go, do = T.RMSprop(5e-4), T.RMSprop(5e-4)
+    dl0, gl0 = T.train_iteration(x, cc, nc, g0, d0, go, do, 3)
+    _, g1, d1 = _models(p)
+    go1, do1 = T.RMSprop(5e-4), T.RMSprop(5e-4)
+    dl1, gl1 = _iteration_by_segments(T, [g1], [d1], [go1], [do1], [(x, cc, nc, 0)], 24, 3, 77, 0)
+    assert float(dl0) == dl1 and float(gl0) == gl1
+    for a, b in zip(g0.get_weights() + d0.get_weights(), g1.get_weights() + d1.get_weights()):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('cuts', [(0, 12, 24), (0, 7, 16, 24)])
+def test_data_parallel_shards_reproduce_the_big_batch(gpu, cuts):
+    """R ranks (emulated on one GPU: replicas + summed gradient buffers) holding row shards of a
+    global batch give the weights of the one-GPU run on the whole batch (same draws: every rank
+    keeps its rows of the GLOBAL z / alpha streams)."""
+    from adversarial_gene_expression_amd import tf_utils as T
+    p = make_problem(G=61, B=24, H=(24, 16), seed=12)
+    x, cc, nc = _f32(p, 'x'), p['cc'], _f32(p, 'nc')
+    _, g0, d0 = _models(p)
+    T.set_seed(5)
+    dl0, gl0 = T.train_iteration(x, cc, nc, g0, d0, T.RMSprop(5e-4), T.RMSprop(5e-4), 2)
+    R = len(cuts) - 1
+    gens, discs = [], []
+    for _ in range(R):
+        _, g, d = _models(p)
+        gens.append(g)
+        discs.append(d)
+    shards = [(x[a:b], cc[a:b], nc[a:b], a) for a, b in zip(cuts[:-1], cuts[1:])]
+    dl1, gl1 = _iteration_by_segments(T, gens, discs, [T.RMSprop(5e-4) for _ in range(R)],
+                                      [T.RMSprop(5e-4) for _ in range(R)], shards, 24, 2, 5, 0)
+    # RMSprop sensitivity (see test_weights_after_steps): a gradient entry ~1e-7 turns a summation-order
+    # difference into an O(lr) difference of its update; stated tolerance as there.
+    assert abs(float(dl0) - dl1) <= 2e-4 and abs(float(gl0) - gl1) <= 2e-4
+    lr = 5e-4
+    for r in range(R):
+        for ref, net, steps in ((g0, gens[r], 1), (d0, discs[r], 2)):
+            a = np.concatenate([w.reshape(-1) for w in ref.get_weights()])
+            b = np.concatenate([w.reshape(-1) for w in net.get_weights()])
+            err = np.abs(a - b)
+            assert np.quantile(err, 0.99) < 2e-6, np.quantile(err, 0.99)   # ~2e3 weights: 99 %
+            assert err.max() <= steps * lr * np.sqrt(10) + 1e-6, err.max()
+        if r:   # replicas stay bit-identical to each other (same summed gradients, same update)
+            for a, b in zip(discs[0].get_weights() + gens[0].get_weights(), discs[r].get_weights() + gens[r].get_weights()):
+                np.testing.assert_array_equal(a, b)
