@@ -59,6 +59,26 @@ def padded_matrix(a):
     return out, ld
 
 
+def world():
+    """(world_size, rank) of the torch.distributed job, (1, 0) outside one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def allreduce_sum(t):
+    """Sum all-reduce of a device tensor (RCCL; via the host under a gloo rehearsal)."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
 class DeviceArray:
     """Result living in HBM; converts lazily (the only host sync is the conversion)."""
 

@@ -180,6 +180,7 @@ SIGNATURES = {
     'agx_triu_pack_f64': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'agx_pearson_sums': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     'agx_gamma_sums': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    'agx_gamma_sums_tiles': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i64, _i64, _vp]),
     'agx_cgan_create': (C.c_int, [C.POINTER(CganConfig), C.POINTER(_vp)]),
     'agx_cgan_destroy': (C.c_int, [_vp]),
     'agx_cgan_workspace_bytes': (_i64, [_vp]),

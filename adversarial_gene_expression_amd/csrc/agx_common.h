@@ -53,6 +53,20 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// decode linear upper-triangular tile index t -> (ti <= tj) over a T x T tile grid
+__device__ __forceinline__ void tri_decode(long long t, int T, int &ti, int &tj) {
+  // row ti starts at offset ti*T - ti*(ti-1)/2
+  double b = 2.0 * T + 1.0;
+  int i = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+  if (i < 0) i = 0;
+  if (i > T - 1) i = T - 1;
+  auto start = [T](long long r) { return r * T - r * (r - 1) / 2; };
+  while (i > 0 && start(i) > t) --i;
+  while (i + 1 < T && start(i + 1) <= t) ++i;
+  ti = i;
+  tj = i + (int)(t - start(i));
+}
+
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

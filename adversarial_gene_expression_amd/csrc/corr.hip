@@ -191,6 +191,34 @@ __global__ void __launch_bounds__(256) gamma_sums_kernel(const float *__restrict
   block_add5(s, 6, sums);
 }
 
+// same sums over a range of the upper-triangular 128x128 tile list of agx_corr_xtx (the tiles one
+// rank owns when the G x G matrix is dealt across GPUs): one block per tile
+__global__ void __launch_bounds__(256) gamma_sums_tiles_kernel(const float *__restrict__ C1, int ld1,
+                                                               const float *__restrict__ C2, int ld2,
+                                                               int G, long long tile_begin, int tiles_1d,
+                                                               double *__restrict__ sums) {
+  int ti, tj;
+  agx::tri_decode(tile_begin + blockIdx.x, tiles_1d, ti, tj);
+  const int i0 = ti * 128, j0 = tj * 128;
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  const int j = j0 + tx;
+  if (j < G) {
+    for (int r = ty; r < 128; r += 2) {
+      const int i = i0 + r;
+      if (i >= G || j <= i) continue;
+      const float fa = 1.0f - C1[(size_t)i * ld1 + j], fb = 1.0f - C2[(size_t)i * ld2 + j];
+      if (isnan(fa) || isnan(fb)) {
+        s[5] += 1.0;
+      } else {
+        const double da = fa, db = fb;
+        s[0] += da; s[1] += db; s[2] += da * da; s[3] += db * db; s[4] += da * db;
+      }
+    }
+  }
+  block_add5(s, 6, sums);
+}
+
 }  // namespace
 
 extern "C" int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
@@ -277,6 +305,21 @@ extern "C" int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const 
   AGX_CHECK_ARG(C1 && C2 && sums && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums: bad argument");
   hipLaunchKernelGGL(gamma_sums_kernel, dim3(std::min(G, 2048)), dim3(256), 0,
                      agx::as_stream(stream), C1, ld1, C2, ld2, G, sums);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_gamma_sums_tiles(void *stream, const float *C1, int32_t ld1, const float *C2,
+                                    int32_t ld2, int32_t G, int64_t tile_begin, int64_t tile_end,
+                                    double *sums) {
+  AGX_CHECK_ARG(C1 && C2 && sums && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums_tiles: bad argument");
+  const int64_t total = agx_corr_num_tiles(G);
+  if (tile_end < 0 || tile_end > total) tile_end = total;
+  AGX_CHECK_ARG(tile_begin >= 0 && tile_begin <= tile_end, "agx_gamma_sums_tiles: bad tile range");
+  if (tile_begin == tile_end) return AGX_OK;
+  hipLaunchKernelGGL(gamma_sums_tiles_kernel, dim3((unsigned)(tile_end - tile_begin)), dim3(256), 0,
+                     agx::as_stream(stream), C1, ld1, C2, ld2, G, (long long)tile_begin,
+                     agx::cdiv(G, 128), sums);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

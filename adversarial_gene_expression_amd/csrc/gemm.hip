@@ -207,19 +207,7 @@ struct Tile {
   }
 };
 
-// decode linear upper-triangular tile index t -> (ti <= tj) over a T x T tile grid
-__device__ __forceinline__ void tri_decode(long long t, int T, int &ti, int &tj) {
-  // row ti starts at offset ti*T - ti*(ti-1)/2
-  double b = 2.0 * T + 1.0;
-  int i = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
-  if (i < 0) i = 0;
-  if (i > T - 1) i = T - 1;
-  auto start = [T](long long r) { return r * T - r * (r - 1) / 2; };
-  while (i > 0 && start(i) > t) --i;
-  while (i + 1 < T && start(i + 1) <= t) ++i;
-  ti = i;
-  tj = i + (int)(t - start(i));
-}
+using agx::tri_decode;
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32>
 __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {

@@ -551,15 +551,11 @@ def _pair(gen, disc, batch, steps=6):
 
 
 def _world():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.get_world_size(), dist.get_rank()
-    return 1, 0
+    return _dev.world()
 
 
 def _allreduce_grads(net):
-    import torch.distributed as dist
-    dist.all_reduce(net.grads)  # RCCL sum over xGMI; loss slots ride along
+    _dev.allreduce_sum(net.grads)  # RCCL sum over xGMI; the loss slots behind the gradients ride along
 
 
 _TRACE_CONSTS = {}

@@ -191,6 +191,15 @@ def correlations_list(x, y, corr_fn=pearson_correlation):
     return upper_diag_list(corr_fn(x, y))
 
 
+def _rank_tile_range(g):
+    """Contiguous share of the upper-triangular 128x128 tile list owned by this rank."""
+    lib = _lib.load()
+    world, rank = _dev.world()
+    total = int(lib.agx_corr_num_tiles(g))
+    per = (total + world - 1) // world
+    return min(total, rank * per), min(total, (rank + 1) * per), world
+
+
 def gamma_coef(x, y):
     """Gamma(D^X, D^Z) = Pearson r between the condensed distance lists
     ``1 - corr``.  Reference ``utils.py:863-873``.
@@ -198,15 +207,32 @@ def gamma_coef(x, y):
     Both G x G matrices stay in HBM.  Without NaNs the five sums are taken
     straight over the two upper triangles (the 2 x G(G-1)/2 lists are never
     built); if any NaN is present the lists are packed with the reference's
-    NaN-dropping and the reference's length assertion applies."""
+    NaN-dropping and the reference's length assertion applies.
+
+    Under torch.distributed (x, y replicated on every rank) the upper-triangular
+    tile list of both matrices is dealt across the ranks: each GPU computes only
+    its tiles of X^T X and Y^T Y and their partial sums; one all-reduce of six
+    fp64 scalars combines them (no matrix is gathered)."""
     lib = _lib.load()
     dt = _in_dtype(x, y)
-    cx, ldx, g = _corr_self_dev(x)
-    cy, ldy, g2 = _corr_self_dev(y)
-    if g != g2:
+    if x.shape[1] != y.shape[1]:
         # lists of different length: reference fails at utils.py:821
         raise AssertionError
+    tb, te, world = _rank_tile_range(x.shape[1])
     sums = _dev.zeros(8, dtype=torch.float64)
+    if world > 1:
+        cx, ldx, g = _corr_self_dev(x, (tb, te))
+        cy, ldy, _ = _corr_self_dev(y, (tb, te))
+        _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, tb, te, ptr(sums)),
+                   'agx_gamma_sums_tiles')
+        _dev.allreduce_sum(sums)
+        s = sums.cpu().numpy()
+        if s[5] == 0:
+            r = _r_from_sums(s, g * (g - 1) // 2)
+            return r if dt == np.float32 else np.float64(r)
+        sums.zero_()        # NaNs present: every rank takes the packed (replicated) path below
+    cx, ldx, g = _corr_self_dev(x)
+    cy, ldy, g2 = _corr_self_dev(y)
     _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, ptr(sums)), 'agx_gamma_sums')
     s = sums.cpu().numpy()
     if s[5] == 0:

@@ -96,16 +96,17 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
     gopt, dopt = T.RMSprop(5e-4), T.RMSprop(5e-4)     # tf_utils.py:285-288
     nbatches = 8
     x, cc, nc = synthetic_batch_pool(G, V, n_num, B * nbatches, seed=100 + rank)
-    T.set_seed(1000 + rank)
+    T.set_seed(1000)       # one global draw stream: every rank keeps its rows of it
     Bg = B * world
 
-    use_graph = world == 1 and not os.environ.get('AGX_BENCH_EAGER')
+    use_graph = not os.environ.get('AGX_BENCH_EAGER')
 
     def iteration(i):
         s = slice((i % nbatches) * B, (i % nbatches + 1) * B)
         xb, cb, nb = x[s], cc[s], nc[s]
-        if use_graph:      # the path train() takes on one GPU: the whole iteration is one hipGraph
-            T.train_iteration(xb, cb, nb, gen, disc, gopt, dopt, nb_critic)
+        if use_graph:      # the path train() takes: one hipGraph per iteration (N > 1: one graph segment
+            # between consecutive gradient all-reduces)
+            T.train_iteration(xb, cb, nb, gen, disc, gopt, dopt, nb_critic, batch_global=Bg, row_lo=rank * B)
             return
         for _ in range(nb_critic):
             z = T.random_normal((B, Z))
@@ -142,12 +143,17 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
         lib.agx_prof_enable(-2)
         return prof_read_all(lib, _lib)
 
+    dbg = (lambda m: print('[bench rank %d] %s' % (rank, m), file=sys.stderr, flush=True)) if os.environ.get('AGX_BENCH_DEBUG') else (lambda m: None)
+    dbg('models built')
     for i in range(warmup):
         iteration(i)
+        dbg('warmup %d queued' % i)
     sync()
+    dbg('warmup done')
     nprobe = 3
     disc_prof = bracketed(-1, nprobe)          # discovery: which kernel class dominates?
     dominant = max(disc_prof, key=lambda k: disc_prof[k]['ms'])
+    dbg('probe done')
     lib.agx_prof_reset()
     sync()
     t0 = time.perf_counter()
@@ -156,7 +162,7 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        t = torch.tensor([dt], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # dominant kernel, timed with HIP events on the launch stream right after the timed region
@@ -183,6 +189,87 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
     del gen, disc, x
     torch.cuda.empty_cache()
     return res
+
+
+def run_corr(world, rank, n_big, G=18154, n_eval=2287):
+    """Correlation evaluation (BASELINE.json metric 'corr GFLOP/s'; configs[3] = 18154 x 100000).
+    (1) gamma_coef at the GTEx evaluation shape (utils.py:863-873 as score_fn calls it every 5 epochs);
+    (2) the X^T X contraction of the big matrix: this rank's contiguous share of the upper-triangular
+        tile list (no collective in the contraction).  FLOP conventions: symmetric N*G*(G+1) (algorithmic)
+        and full 2*N*G^2 (what the reference's np.dot executes)."""
+    import torch
+    from adversarial_gene_expression_amd import _dev, _lib, utils as U
+    lib = _lib.load()
+    out = {}
+    g = torch.Generator(device='cuda').manual_seed(7)
+    f = torch.randn(n_eval, 32, device='cuda', generator=g)
+    xa = f @ torch.randn(32, G, device='cuda', generator=g) + 0.5 * torch.randn(n_eval, G, device='cuda', generator=g)
+    xb = xa + 0.3 * torch.randn(n_eval, G, device='cuda', generator=g)
+    U.gamma_coef(xa, xb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        gam = U.gamma_coef(xa, xb)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out['gamma_coef_eval'] = dict(shape=[n_eval, G], ms=dt * 1e3, value=float(gam),
+                                  tflops_sym=2 * n_eval * G * (G + 1.0) / dt / 1e12)
+    del xa, xb, f
+    torch.cuda.empty_cache()
+    # big matrix, generated in row chunks to bound the temporary memory
+    ld = _dev.r4(G)
+    x = torch.empty((n_big, ld), device='cuda')
+    for r0 in range(0, n_big, 8192):
+        r1 = min(n_big, r0 + 8192)
+        x[r0:r1] = torch.randn(r1 - r0, ld, device='cuda', generator=g)
+    st = _dev.stream()
+    mean, std = _dev.empty(G), _dev.empty(G)
+    ws = _dev.empty(2 * G, dtype=torch.float64)
+    xs = torch.empty_like(x)
+    c = _dev.empty((G, ld))
+    total = int(lib.agx_corr_num_tiles(G))
+    per = (total + world - 1) // world
+    tb, te = min(total, rank * per), min(total, (rank + 1) * per)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def once():
+        ev[0].record()
+        _lib.check(lib.agx_colstats(st, x.data_ptr(), ld, n_big, G, mean.data_ptr(), std.data_ptr(), ws.data_ptr()))
+        _lib.check(lib.agx_standardize(st, x.data_ptr(), ld, n_big, G, mean.data_ptr(), std.data_ptr(), xs.data_ptr(), ld))
+        ev[1].record()
+        _lib.check(lib.agx_corr_xtx(st, xs.data_ptr(), ld, n_big, G, 1.0 / n_big, c.data_ptr(), ld, tb, te))
+        ev[2].record()
+    once()
+    torch.cuda.synchronize()
+    once()
+    torch.cuda.synchronize()
+    t_std, t_xtx = ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([t_std, t_xtx], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_std, t_xtx = float(t[0]), float(t[1])
+    sym = n_big * G * (G + 1.0)
+    out['pearson_big'] = dict(shape=[n_big, G], n_gpus=world, xtx_ms=t_xtx * 1e3, standardize_ms=t_std * 1e3,
+                              tflops_sym=sym / t_xtx / 1e12, tflops_full_convention=2.0 * n_big * G * G / t_xtx / 1e12,
+                              mfma_frac=sym / t_xtx / 1e12 / MFMA_F32_PEAK_TF,
+                              standardize_gbs=12.0 * n_big * G / t_std / 1e9,
+                              tiles=[tb, te, total])
+    return out
+
+
+def corr_cpu_baseline(G=18154, n_eval=2287):
+    """NumPy restatement of utils.py:808-824 (checked against the reference's goldens) at the GTEx
+    evaluation shape on this host's cores."""
+    from oracle import corr_oracle as CO
+    rs = np.random.RandomState(0)
+    x = rs.randn(n_eval, G).astype(np.float32)
+    t0 = time.perf_counter()
+    CO.pearson_correlation(x, x)
+    dt = time.perf_counter() - t0
+    return dict(value=2.0 * n_eval * G * G / dt / 1e9, unit='GFLOP/s (2NG^2 convention)', seconds=dt,
+                cores=os.cpu_count(), kind='port', sample='one pearson_correlation(x, x) at N=%d, G=%d' % (n_eval, G))
 
 
 def measured_traffic(kernel, B):
@@ -240,6 +327,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--secondary', dest='secondary', action='store_true', default=None)
     ap.add_argument('--no-secondary', dest='secondary', action='store_false')
+    ap.add_argument('--corr-n', type=int, default=100000, help='samples of the big correlation matrix (0 = skip)')
     a = ap.parse_args()
 
     import torch
@@ -248,8 +336,13 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         import torch.distributed as dist
+        backend = os.environ.get('AGX_DIST_BACKEND', 'nccl')   # 'gloo' lets several ranks share one GPU (rehearsal only)
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world and rank == 0 and world == 1 and a.gpus > 1:
         print('bench.py: --gpus %d needs torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus), file=sys.stderr)
         sys.exit(2)
@@ -276,8 +369,15 @@ def main():
                              'roofline': s['roofline'], 'kernel_us_per_iter': s['kernel_us_per_iter'],
                              'whole_iter_tflops': s['whole_iter_tflops'],
                              'whole_iter_mfma_frac': s['whole_iter_mfma_frac']}
+    if a.corr_n > 0:
+        try:
+            corr = run_corr(world, rank, a.corr_n)
+        except Exception as e:                      # never lose the train line to the secondary metric
+            corr = {'error': repr(e)[:200]}
+        line['corr'] = corr
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(a.workload, a.batch)
+        line['corr_cpu_baseline'] = corr_cpu_baseline()
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

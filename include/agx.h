@@ -274,6 +274,11 @@ int agx_pearson_sums(void *stream, const float *a, const float *b, int64_t n, in
  * packed path to reproduce the reference's NaN-dropping).  utils.py:863-873 fused. */
 int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const float *C2, int32_t ld2,
                    int32_t G, double *sums);
+/* The same six sums over tiles [tile_begin, tile_end) of agx_corr_xtx's upper-triangular 128x128
+ * tile list only (the share of one rank when the matrix is dealt across GPUs; the ranks' sums
+ * add up to agx_gamma_sums' and are combined with one all-reduce of 6 doubles). */
+int agx_gamma_sums_tiles(void *stream, const float *C1, int32_t ld1, const float *C2, int32_t ld2,
+                         int32_t G, int64_t tile_begin, int64_t tile_end, double *sums);
 
 /* ---- whole train step: tf_utils.py:186-258 ------------------------------ */
 typedef struct agx_mlp_desc {

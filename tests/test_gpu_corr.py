@@ -123,3 +123,30 @@ def test_tile_ranges_compose(gpu):
         lo, hi = r * nt // 4, (r + 1) * nt // 4
         _lib.check(lib.agx_corr_xtx(_dev.stream(), ptr(xs), ld, n, g, 1.0 / n, ptr(c), ldc, lo, hi))
     assert torch.equal(c[:, :g], full[:, :g])
+
+
+def test_gamma_sums_over_tile_ranges_add_up(gpu):
+    """Multi-GPU gamma: each 'rank' computes only its tiles of both matrices and the six partial sums
+    over them; the partials add up to the single-GPU sums (so one 6-scalar all-reduce suffices)."""
+    import torch
+    from adversarial_gene_expression_amd import _dev, _lib, utils as U
+    from adversarial_gene_expression_amd._dev import ptr
+    lib = _lib.load()
+    rs = np.random.RandomState(9)
+    x, y = lowrank(rs, 90, 700, k=8), lowrank(rs, 70, 700, k=8)
+    cx, ldx, g = U._corr_self_dev(x)
+    cy, ldy, _ = U._corr_self_dev(y)
+    ref = _dev.zeros(8, dtype=torch.float64)
+    _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, ptr(ref)))
+    nt = int(lib.agx_corr_num_tiles(g))
+    acc = _dev.zeros(8, dtype=torch.float64)
+    for r in range(3):
+        lo, hi = r * nt // 3, (r + 1) * nt // 3
+        px, _, _ = U._corr_self_dev(x, (lo, hi))     # only this rank's tiles are defined
+        py, _, _ = U._corr_self_dev(y, (lo, hi))
+        _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(px), ldx, ptr(py), ldy, g, lo, hi, ptr(acc)))
+    a, b = acc.cpu().numpy(), ref.cpu().numpy()
+    assert a[5] == 0 and b[5] == 0
+    np.testing.assert_allclose(a[:5], b[:5], rtol=1e-12)
+    r = U._r_from_sums(a, g * (g - 1) // 2)
+    assert abs(float(r) - float(CO.gamma_coef(x, y))) < 2e-5
