@@ -67,6 +67,15 @@ __device__ __forceinline__ void tri_decode(long long t, int T, int &ti, int &tj)
   tj = i + (int)(t - start(i));
 }
 
+// XCD-aware workgroup order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2),
+// so ids b and b+8 share an L2.  This bijection gives the workgroups of one XCD a CONTIGUOUS range of
+// logical ids: neighbours in the logical order (same operand rows / same split-K slice) then hit the
+// same L2 instead of fetching the same lines into eight of them.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_logical_id(int linear, int total) {
+  const int q = total >> 3, r = total & 7, x = linear & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (linear >> 3);
+}
+
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

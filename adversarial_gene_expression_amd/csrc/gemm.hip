@@ -202,6 +202,42 @@ struct Tile {
     }
   }
 
+  // ---- interior fast path (full tile inside the operand, 16-B aligned): the lane's element offsets
+  // are computed once, the per-K-tile address is a wave-uniform base + that offset (no clamps, no
+  // 64-bit vector multiply per load), and the LDS store needs no masking
+  __device__ static __forceinline__ void lane_offsets(int ld, int tid, int (&off)[PT]) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int r, k;
+      coords(tid + i * NT, r, k);
+      off[i] = KC ? r * ld + k : k * ld + r;
+    }
+  }
+  __device__ static __forceinline__ const float *ubase(const float *src, int ld, int r0, int k0) {
+    return KC ? src + (size_t)r0 * ld + k0 : src + (size_t)k0 * ld + r0;
+  }
+  __device__ static __forceinline__ void load_fast(const float *__restrict__ ub, const int (&off)[PT],
+                                                   float4 (&reg)[PT]) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) reg[i] = *reinterpret_cast<const float4 *>(ub + off[i]);
+  }
+  __device__ static __forceinline__ void store_fast(float *lds, int tid, const float4 (&reg)[PT]) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int r, k;
+      coords(tid + i * NT, r, k);
+      if (KC) {
+        float *d = lds + r * (BK + 1) + k;
+        d[0] = reg[i].x;
+        d[1] = reg[i].y;
+        d[2] = reg[i].z;
+        d[3] = reg[i].w;
+      } else {
+        *reinterpret_cast<float4 *>(lds + k * ROWS + r) = reg[i];
+      }
+    }
+  }
+
   __device__ static __forceinline__ float frag(const float *lds, int r, int k) {
     return KC ? lds[r * (BK + 1) + k] : lds[k * ROWS + r];
   }
@@ -209,7 +245,7 @@ struct Tile {
 
 using agx::tri_decode;
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, int DBG = 0>
 __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -224,16 +260,20 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  int tm, tn;
+  int tm, tn, z;
   if (SYRK) {
-    tri_decode(p.tile_begin + blockIdx.x, p.tiles_1d, tm, tn);
+    tri_decode(p.tile_begin + agx::xcd_logical_id(blockIdx.x, gridDim.x), p.tiles_1d, tm, tn);
+    z = 0;
   } else {
+    // logical order: split-K slice major, then tile row, then tile column
+    const int lid = agx::xcd_logical_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     const int tiles_n = (p.N + BN - 1) / BN;
-    tm = blockIdx.x / tiles_n;
-    tn = blockIdx.x % tiles_n;
+    const int t = lid % (int)gridDim.x;
+    z = lid / (int)gridDim.x;
+    tm = t / tiles_n;
+    tn = t % tiles_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.y;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -255,17 +295,9 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   }
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    const float *cA = smem + (t & 1) * STAGE;
-    const float *cB = cA + TileA::LDS_FLOATS;
-    const bool more = (t + 1 < nt);
-    if (more) {
-      const int k0 = kbeg + (t + 1) * BK;
-      TileA::load(p.A, p.lda, m0, p.M, k0, kend, tid, ra);
-      TileB::load(p.B, p.ldb, n0, p.N, k0, kend, tid, rb);
-    }
-    // fragment reads run one k-pair ahead of the MFMAs that consume them (register double buffer):
-    // with one wave per SIMD nothing else hides the LDS latency between two MFMA groups
+  // MFMAs of one staged K-tile.  Fragment reads run one k-pair ahead of the MFMAs that consume them
+  // (register double buffer): with one wave per SIMD nothing else hides the LDS latency.
+  auto mma_tile = [&](const float *cA, const float *cB) {
     float fa[2][TM], fb[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = TileA::frag(cA, (wm * TM + i) * 32 + l31, lh);
@@ -288,6 +320,46 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  int t = 0;
+  if (VEC && DBG == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
+    // interior tile: K-tiles 1 .. nfull-1 are loaded without clamps and stored without masks
+    const int nfull = (kend - kbeg) / BK;
+    int offa[TileA::PT], offb[TileB::PT];
+    TileA::lane_offsets(p.lda, tid, offa);
+    TileB::lane_offsets(p.ldb, tid, offb);
+    for (; t + 1 < nfull; ++t) {
+      const float *cA = smem + (t & 1) * STAGE;
+      const int k0 = kbeg + (t + 1) * BK;
+      TileA::load_fast(TileA::ubase(p.A, p.lda, m0, k0), offa, ra);
+      TileB::load_fast(TileB::ubase(p.B, p.ldb, n0, k0), offb, rb);
+      mma_tile(cA, cA + TileA::LDS_FLOATS);
+      float *nA = smem + ((t + 1) & 1) * STAGE;
+      TileA::store_fast(nA, tid, ra);
+      TileB::store_fast(nA + TileA::LDS_FLOATS, tid, rb);
+      __syncthreads();
+    }
+  }
+  for (; t < nt; ++t) {
+    const float *cA = smem + (t & 1) * STAGE;
+    const float *cB = cA + TileA::LDS_FLOATS;
+    const bool more = (t + 1 < nt);
+    if (more && DBG != 1 && DBG != 3) {
+      const int k0 = kbeg + (t + 1) * BK;
+      TileA::load(p.A, p.lda, m0, p.M, k0, kend, tid, ra);
+      TileB::load(p.B, p.ldb, n0, p.N, k0, kend, tid, rb);
+    }
+    mma_tile(cA, cB);
+    if (DBG >= 2) {  // timing ablation only (wrong results): no LDS refill, no barrier
+      if (DBG == 2) {
+#pragma unroll
+        for (int q = 0; q < TileA::PT; ++q) asm volatile("" ::"v"(ra[q].x), "v"(ra[q].w));
+#pragma unroll
+        for (int q = 0; q < TileB::PT; ++q) asm volatile("" ::"v"(rb[q].x), "v"(rb[q].w));
+      }
+      continue;
     }
     if (more) {
       float *nA = smem + ((t + 1) & 1) * STAGE;
@@ -517,8 +589,9 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + 31) / 32;
-  const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
-  const int z = blockIdx.y;
+  const int lid = agx::xcd_logical_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bt = lid % (int)gridDim.x, z = lid / (int)gridDim.x;  // all tiles of one K slice share an XCD's L2
+  const int m0 = (bt / tiles_n) * 32, n0 = (bt % tiles_n) * 32;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int ngroups = (kend - kbeg + 7) / 8;
@@ -607,8 +680,9 @@ template <bool TA, bool TB, bool VEC, int TM, int TN, int U>
 __global__ void __launch_bounds__(64) gemm_wave_kernel(const KParams p) {
   const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + 32 * TN - 1) / (32 * TN);
-  const int m0 = (blockIdx.x / tiles_n) * 32 * TM, n0 = (blockIdx.x % tiles_n) * 32 * TN;
-  const int z = blockIdx.y;
+  const int lid = agx::xcd_logical_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bt = lid % (int)gridDim.x, z = lid / (int)gridDim.x;
+  const int m0 = (bt / tiles_n) * 32 * TM, n0 = (bt % tiles_n) * 32 * TN;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int ngroups = (kend - kbeg + 7) / 8;
@@ -825,7 +899,9 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
   pl.wtm = pl.wtn = 1;
   pl.bm = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : 32);
   pl.bn = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : (cfg == 2 ? 128 : 32));
-  if (cfg >= 8) {
+  if (cfg >= 20) {
+    pl.bm = pl.bn = 128;
+  } else if (cfg >= 8) {
     pl.wtm = kWaveTiles[cfg - 8][0];
     pl.wtn = kWaveTiles[cfg - 8][1];
     pl.bm = 32 * pl.wtm;
@@ -900,7 +976,7 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
   AGX_CHECK_ARG(g->ldc >= g->N, "agx_gemm_f32: ldc %d < N %d", g->ldc, g->N);
   AGX_CHECK_ARG(!g->addrow || (g->addmod > 0 && g->ldadd >= g->N), "agx_gemm_f32: bad addrow");
   AGX_CHECK_ARG(!g->mask || g->ldmask >= g->N, "agx_gemm_f32: bad mask ld");
-  AGX_CHECK_ARG(g->force_cfg <= 15, "agx_gemm_f32: force_cfg out of range");
+  AGX_CHECK_ARG(g->force_cfg <= 23, "agx_gemm_f32: force_cfg out of range");
 
   KParams p{};
   p.A = g->A; p.B = g->B; p.C = g->C;
@@ -952,7 +1028,16 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
     rc = launch_layout<128, 128, 2, 2, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 7)
     rc = launch_layout<128, 128, 2, 4, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
-  else if (pl.cfg >= 8) {
+  else if (pl.cfg >= 20) {  // timing ablations of the TN 128x128 kernel (tools/ only; results are wrong)
+    AGX_CHECK_ARG(g->ta && !g->tb && vec, "agx_gemm_f32: ablation configs exist for aligned TN only");
+    dim3 grid(pl.tiles, p.splitk, 1), block(256, 1, 1);
+    constexpr size_t lds = 2 * (size_t)(128 * 32 + 32 * 128) * sizeof(float);
+    if (pl.cfg == 21) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, true, false, true, false, 32, 1>), grid, block, lds, st, p);
+    else if (pl.cfg == 22) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, true, false, true, false, 32, 2>), grid, block, lds, st, p);
+    else if (pl.cfg == 23) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, true, false, true, false, 32, 3>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, true, false, true, false, 32, 0>), grid, block, lds, st, p);
+    rc = AGX_OK;
+  } else if (pl.cfg >= 8) {
     if (!g->ta && !g->tb) rc = launch_wave<false, false>(st, p, vec, pl.wtm, pl.wtn);
     else if (!g->ta && g->tb) rc = launch_wave<false, true>(st, p, vec, pl.wtm, pl.wtn);
     else rc = launch_wave<true, false>(st, p, vec, pl.wtm, pl.wtn);
