@@ -111,19 +111,42 @@ __device__ __forceinline__ void epilogue_column(const KParams &p, const int (&ro
 }
 
 // ---- operand tile: ROWS x BK --------------------------------------------
+// LDS image, the same for both source orientations: element (row r, k) lives at dword
+//     ((k/4) * ROWS + swz(r, k/4)) * 4 + k%4 ,   swz(r, q) = r ^ (((r >> 3) & 3) ^ (q & 7))
+// i.e. [k-quad][row][4 consecutive k].  An MFMA lane (row l31, half lh) fetches the four k of
+// k-quad 2g+lh with ONE ds_read_b128 and feeds four 32x32x2 MFMAs from it (A and B use the same
+// k order 8g + 4lh + e, so the product is unchanged): one LDS instruction per four MFMAs per
+// fragment instead of one per MFMA - with one wave per SIMD every non-MFMA instruction costs
+// issue time the matrix pipe cannot hide.  The XOR swizzle (low 3 row bits only, a bijection
+// inside every 8-row group) makes all three access patterns hit distinct bank quads:
+//   - fragment read: 16 consecutive rows of one k-quad;
+//   - k-contiguous source: one ds_write_b128 per float4, 8 lanes = 8 k-quads of one row;
+//   - row-contiguous source: a thread owns a 4(row) x 4(k) block, transposes it in registers and
+//     writes 4 ds_write_b128 (lane j -> rows 4j+e).
 template <int ROWS, bool KC, int NT, bool VEC, int BK>
 struct Tile {
   static constexpr int F4 = ROWS * BK / 4;
   static constexpr int PT = F4 / NT;  // float4 per thread
   static_assert(F4 % NT == 0, "tile must divide over the block");
-  static constexpr int LDS_FLOATS = KC ? ROWS * (BK + 1) : BK * ROWS;
+  static constexpr bool BLOCK4 = !KC && (PT % 4 == 0);  // row-contiguous: 4x4 register transpose
+  static constexpr int LDS_FLOATS = BK * ROWS;
 
-  // (r, k) of the first element of float4 number q
-  __device__ static __forceinline__ void coords(int q, int &r, int &k) {
+  __device__ static __forceinline__ int lds_quad(int r, int kq) {  // float4 index of (row, k-quad)
+    return kq * ROWS + (r ^ (((r >> 3) & 3) ^ (kq & 7)));
+  }
+
+  // (r, k) of the first element of float4 number i of thread tid
+  __device__ static __forceinline__ void coords(int tid, int i, int &r, int &k) {
     if (KC) {
+      const int q = tid + i * NT;
       r = q / (BK / 4);
       k = (q % (BK / 4)) * 4;
+    } else if (BLOCK4) {
+      const int blk = tid + (i >> 2) * NT;  // 4x4 block: rows 4*rq.., k-quad kq; float4 i&3 = one k of it
+      r = (blk % (ROWS / 4)) * 4;
+      k = (blk / (ROWS / 4)) * 4 + (i & 3);
     } else {
+      const int q = tid + i * NT;
       k = q / (ROWS / 4);
       r = (q % (ROWS / 4)) * 4;
     }
@@ -138,7 +161,7 @@ struct Tile {
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       int r, k;
-      coords(tid + i * NT, r, k);
+      coords(tid, i, r, k);
       const int gr = r0 + r, gk = k0 + k;
       float4 v;
       if (KC) {
@@ -172,12 +195,49 @@ struct Tile {
     }
   }
 
+  // registers -> LDS image (no masking)
+  __device__ static __forceinline__ void store_fast(float *lds, int tid, const float4 (&reg)[PT]) {
+    float4 *l4 = reinterpret_cast<float4 *>(lds);
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        int r, k;
+        coords(tid, i, r, k);
+        l4[lds_quad(r, k >> 2)] = reg[i];
+      }
+    } else if (BLOCK4) {
+#pragma unroll
+      for (int b = 0; b < PT / 4; ++b) {
+        int r, k;
+        coords(tid, 4 * b, r, k);
+        const float4 c0 = reg[4 * b], c1 = reg[4 * b + 1], c2 = reg[4 * b + 2], c3 = reg[4 * b + 3];
+        l4[lds_quad(r, k >> 2)] = make_float4(c0.x, c1.x, c2.x, c3.x);
+        l4[lds_quad(r + 1, k >> 2)] = make_float4(c0.y, c1.y, c2.y, c3.y);
+        l4[lds_quad(r + 2, k >> 2)] = make_float4(c0.z, c1.z, c2.z, c3.z);
+        l4[lds_quad(r + 3, k >> 2)] = make_float4(c0.w, c1.w, c2.w, c3.w);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        int r, k;
+        coords(tid, i, r, k);
+        const int kq = k >> 2, e = k & 3;
+        lds[lds_quad(r, kq) * 4 + e] = reg[i].x;
+        lds[lds_quad(r + 1, kq) * 4 + e] = reg[i].y;
+        lds[lds_quad(r + 2, kq) * 4 + e] = reg[i].z;
+        lds[lds_quad(r + 3, kq) * 4 + e] = reg[i].w;
+      }
+    }
+  }
+
+  // masked form for edge tiles / the K tail: zero what lies outside the operand, then store
   __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[PT], int r0,
                                                int R, int k0, int kend) {
+    float4 m[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       int r, k;
-      coords(tid + i * NT, r, k);
+      coords(tid, i, r, k);
       const int gr = r0 + r, gk = k0 + k;
       float4 v = reg[i];
       if (KC) {
@@ -186,20 +246,16 @@ struct Tile {
         v.y = (rv && gk + 1 < kend) ? v.y : 0.f;
         v.z = (rv && gk + 2 < kend) ? v.z : 0.f;
         v.w = (rv && gk + 3 < kend) ? v.w : 0.f;
-        float *d = lds + r * (BK + 1) + k;  // odd stride: 4 scalar stores, conflict free
-        d[0] = v.x;
-        d[1] = v.y;
-        d[2] = v.z;
-        d[3] = v.w;
       } else {
         const bool kv = gk < kend;
         v.x = (kv && gr < R) ? v.x : 0.f;
         v.y = (kv && gr + 1 < R) ? v.y : 0.f;
         v.z = (kv && gr + 2 < R) ? v.z : 0.f;
         v.w = (kv && gr + 3 < R) ? v.w : 0.f;
-        *reinterpret_cast<float4 *>(lds + k * ROWS + r) = v;
       }
+      m[i] = v;
     }
+    store_fast(lds, tid, m);
   }
 
   // ---- interior fast path (full tile inside the operand, 16-B aligned): the lane's element offsets
@@ -209,7 +265,7 @@ struct Tile {
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       int r, k;
-      coords(tid + i * NT, r, k);
+      coords(tid, i, r, k);
       off[i] = KC ? r * ld + k : k * ld + r;
     }
   }
@@ -221,25 +277,10 @@ struct Tile {
 #pragma unroll
     for (int i = 0; i < PT; ++i) reg[i] = *reinterpret_cast<const float4 *>(ub + off[i]);
   }
-  __device__ static __forceinline__ void store_fast(float *lds, int tid, const float4 (&reg)[PT]) {
-#pragma unroll
-    for (int i = 0; i < PT; ++i) {
-      int r, k;
-      coords(tid + i * NT, r, k);
-      if (KC) {
-        float *d = lds + r * (BK + 1) + k;
-        d[0] = reg[i].x;
-        d[1] = reg[i].y;
-        d[2] = reg[i].z;
-        d[3] = reg[i].w;
-      } else {
-        *reinterpret_cast<float4 *>(lds + k * ROWS + r) = reg[i];
-      }
-    }
-  }
 
-  __device__ static __forceinline__ float frag(const float *lds, int r, int k) {
-    return KC ? lds[r * (BK + 1) + k] : lds[k * ROWS + r];
+  // the four k (8g + 4*lh + 0..3) of row r for k-group g: one ds_read_b128
+  __device__ static __forceinline__ float4 frag4(const float *lds, int r, int g, int lh) {
+    return reinterpret_cast<const float4 *>(lds)[lds_quad(r, 2 * g + lh)];
   }
 };
 
@@ -295,30 +336,36 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   }
   __syncthreads();
 
-  // MFMAs of one staged K-tile.  Fragment reads run one k-pair ahead of the MFMAs that consume them
-  // (register double buffer): with one wave per SIMD nothing else hides the LDS latency.
+  // MFMAs of one staged K-tile: per 8-k group one ds_read_b128 per fragment, then 4 x TM x TN MFMAs.
+  // The reads of group g+1 are issued before the MFMAs of group g (register double buffer).
   auto mma_tile = [&](const float *cA, const float *cB) {
-    float fa[2][TM], fb[2][TN];
+    constexpr int NG = BK / 8;
+    float4 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = TileA::frag(cA, (wm * TM + i) * 32 + l31, lh);
+    for (int i = 0; i < TM; ++i) fa[0][i] = TileA::frag4(cA, (wm * TM + i) * 32 + l31, 0, lh);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = TileB::frag(cB, (wn * TN + j) * 32 + l31, lh);
+    for (int j = 0; j < TN; ++j) fb[0][j] = TileB::frag4(cB, (wn * TN + j) * 32 + l31, 0, lh);
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < BK / 2) {
-        const int k = 2 * (kk + 1) + lh;
+    for (int g = 0; g < NG; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < NG) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nxt][i] = TileA::frag(cA, (wm * TM + i) * 32 + l31, k);
+        for (int i = 0; i < TM; ++i) fa[nxt][i] = TileA::frag4(cA, (wm * TM + i) * 32 + l31, g + 1, lh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nxt][j] = TileB::frag(cB, (wn * TN + j) * 32 + l31, k);
+        for (int j = 0; j < TN; ++j) fb[nxt][j] = TileB::frag4(cB, (wn * TN + j) * 32 + l31, g + 1, lh);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (hipcc sinks them otherwise)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float4 &a4 = fa[cur][i], &b4 = fb[cur][j];
+            const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+            const float bv = e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w));
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -897,8 +944,8 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
   }
   pl.cfg = cfg;
   pl.wtm = pl.wtn = 1;
-  pl.bm = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : 32);
-  pl.bn = (cfg == 0 || cfg >= 5) ? 128 : (cfg == 1 ? 64 : (cfg == 2 ? 128 : 32));
+  pl.bm = (cfg == 0 || cfg >= 4) ? 128 : (cfg == 1 ? 64 : 32);
+  pl.bn = (cfg == 0 || cfg >= 4) ? 128 : (cfg == 1 ? 64 : (cfg == 2 ? 128 : 32));
   if (cfg >= 20) {
     pl.bm = pl.bn = 128;
   } else if (cfg >= 8) {
@@ -922,7 +969,7 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
       }
     } else {
       // workgroups that can be resident at once (LDS-limited): one round of blocks, no tail round
-      const int slots = cus * ((cfg == 0 || cfg == 5) ? 2 : 4);
+      const int slots = cus * (cfg == 4 ? 1 : ((cfg == 0 || cfg == 5) ? 2 : 4));
       if (pl.tiles * 2 <= slots && ktiles >= 32) {
         sk = slots / pl.tiles;                 // fill the resident slots exactly once
         if (sk > ktiles / 4) sk = ktiles / 4;  // keep >= 4 K-tiles per slice
@@ -954,6 +1001,7 @@ int gemm_prepare_device() {
   AGX_TRY((prepare_cfg<128, 128, 2, 4>()));
   AGX_TRY((prepare_cfg<128, 128, 2, 2, 16>()));
   AGX_TRY((prepare_cfg<128, 128, 2, 4, 16>()));
+  AGX_TRY((prepare_cfg<128, 128, 2, 2, 64>()));
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, true, true>()));
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, false, true>()));
   return AGX_OK;
@@ -1026,6 +1074,8 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
     rc = launch_layout<128, 128, 2, 4>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 6)
     rc = launch_layout<128, 128, 2, 2, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
+  else if (pl.cfg == 4)
+    rc = launch_layout<128, 128, 2, 2, 64>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 7)
     rc = launch_layout<128, 128, 2, 4, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg >= 20) {  // timing ablations of the TN 128x128 kernel (tools/ only; results are wrong)
