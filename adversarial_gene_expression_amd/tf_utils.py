@@ -825,6 +825,20 @@ def _mean32(device_scalars):
     return np.float32(total / np.float32(len(vals)))
 
 
+def make_score_fn(x_test, cat_covs_test, num_covs_test):
+    """Device-resident form of the reference scripts' ``score_fn`` closure (gtex_tcga_gan.py:97-108):
+    ``score_fn(x_test, cc, nc)(gen) == gamma_coef(x_test, predict(cc, nc, gen))`` with x_test's
+    correlation matrix cached in HBM and the generated matrix never copied to the host."""
+    from .utils import GammaScorer
+    scorer = GammaScorer(x_test)
+    cc = _dev.to_dev(cat_covs_test, torch.int32)
+    nc = _dev.to_dev(num_covs_test)
+
+    def _score(gen):
+        return scorer(predict(cc, nc, gen, training=True).tensor)
+    return _score
+
+
 def predict(cc, nc, gen, z=None, training=False):
     """Make predictions (reference ``tf_utils.py:359-376``): NumPy out unless ``training``."""
     nb_samples = cc.shape[0]

@@ -243,3 +243,52 @@ def gamma_coef(x, y):
         assert lx.shape[0] == ly.shape[0]
         r = _pearson_1d_dev(lx, ly, one_minus=True)
     return r if dt == np.float32 else np.float64(r)
+
+
+class GammaScorer:
+    """``gamma_coef(x_test, .)`` with the fixed side cached in HBM.
+
+    The reference's ``score_fn`` closure (gtex_tcga_gan.py:97-108, ecoli_gan.py:62-74) calls
+    ``gamma_coef(x_test, x_gen)`` every 5 epochs and recomputes the correlation matrix of the
+    never-changing ``x_test`` each time (utils.py:870).  Here that matrix (this rank's tiles of it
+    under torch.distributed) is computed once; every call then costs one standardise + X^T X of the
+    generated matrix and one pass of fused sums.  Accepts host arrays or device tensors
+    (``predict(..., training=True)``), so the generated samples never leave the GPU.  Results are
+    those of ``gamma_coef`` (same kernels, same summation order)."""
+
+    def __init__(self, x_test):
+        self.dtype = _in_dtype(x_test)
+        self.g = x_test.shape[1]
+        self.tb, self.te, self.world = _rank_tile_range(self.g)
+        self._x = x_test if self.world > 1 else None     # NaN fallback of the sharded path needs the input again
+        rng = (self.tb, self.te) if self.world > 1 else None
+        self.cx, self.ldx, _ = _corr_self_dev(x_test, rng)
+        self._full = self.cx if self.world == 1 else None
+
+    def __call__(self, x_gen):
+        lib = _lib.load()
+        if x_gen.shape[1] != self.g:
+            raise AssertionError
+        sums = _dev.zeros(8, dtype=torch.float64)
+        g = self.g
+        if self.world > 1:
+            cy, ldy, _ = _corr_self_dev(x_gen, (self.tb, self.te))
+            _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(self.cx), self.ldx, ptr(cy), ldy, g, self.tb, self.te,
+                                                ptr(sums)), 'agx_gamma_sums_tiles')
+            _dev.allreduce_sum(sums)
+            s = sums.cpu().numpy()
+            if s[5] != 0:
+                return gamma_coef(self._x, x_gen)
+        else:
+            cy, ldy, _ = _corr_self_dev(x_gen)
+            _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(self.cx), self.ldx, ptr(cy), ldy, g, ptr(sums)),
+                       'agx_gamma_sums')
+            s = sums.cpu().numpy()
+            if s[5] != 0:
+                lx = _triu_pack_dev(self.cx, self.ldx, g)
+                ly = _triu_pack_dev(cy, ldy, g)
+                assert lx.shape[0] == ly.shape[0]
+                r = _pearson_1d_dev(lx, ly, one_minus=True)
+                return r if self.dtype == np.float32 else np.float64(r)
+        r = _r_from_sums(s, g * (g - 1) // 2)
+        return r if self.dtype == np.float32 else np.float64(r)

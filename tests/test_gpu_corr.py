@@ -150,3 +150,30 @@ def test_gamma_sums_over_tile_ranges_add_up(gpu):
     np.testing.assert_allclose(a[:5], b[:5], rtol=1e-12)
     r = U._r_from_sums(a, g * (g - 1) // 2)
     assert abs(float(r) - float(CO.gamma_coef(x, y))) < 2e-5
+
+
+def test_device_resident_scorer_equals_gamma_coef(gpu):
+    """GammaScorer / make_score_fn (x_test's matrix cached, generated matrix kept in HBM) return
+    exactly gamma_coef's value, for host and device inputs, and follow the NaN path too."""
+    from adversarial_gene_expression_amd import _dev, tf_utils as T, utils as U
+    rs = np.random.RandomState(21)
+    x, y = lowrank(rs, 60, 300, k=6), lowrank(rs, 45, 300, k=6)
+    sc = U.GammaScorer(x)
+    want = U.gamma_coef(x, y)
+    assert sc(y) == want and sc(_dev.to_dev(y)) == want
+    assert abs(float(want) - float(CO.gamma_coef(x, y))) < 2e-5
+    yc = y.copy()
+    yc[:, 7] = 1.0                                  # zero-variance gene: NaN row/column, packed path
+    with pytest.raises(AssertionError):            # NaN-dropping shortens one list: utils.py:821 fires
+        CO.gamma_coef(x, yc)
+    with pytest.raises(AssertionError):
+        sc(yc)
+    # the closure of gtex_tcga_gan.py:97-108 on top of it
+    gen = T.Generator(300, [15, 3], 1, [16, 8], 6, seed=3)
+    cc = np.stack([rs.randint(0, v, 60) for v in (15, 3)], 1).astype(np.int32)
+    nc = np.zeros((60, 1), np.float32)
+    T.set_seed(9)
+    s1 = T.make_score_fn(x, cc, nc)(gen)
+    T.set_seed(9)
+    s2 = U.gamma_coef(x, T.predict(cc, nc, gen))
+    assert s1 == s2
