@@ -499,7 +499,7 @@ __device__ __forceinline__ void colsum_block(const float *__restrict__ A, int ld
 
 __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j) {
   __shared__ float red[16][64];
-  __shared__ float svec[4096];
+  __shared__ float svec[4096];   // [0,2048): partial / final column sums, [2048,4096): row match flags
   int blk = blockIdx.x;
   for (int c = 0; c < j.n_colsum; ++c) {
     const int nb = (j.cs_H[c] + 63) / 64;
@@ -531,30 +531,49 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
       }
       const int H = j.emb_H;
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      float *part = svec, *sfin = svec + 1024;
+      float *part = svec, *sfin = H <= 512 ? svec + 1024 : svec;
       // s[k] = sum over the matching rows of D[r,k]; narrow layers split the rows over 1024/Hp
       // thread groups whose partials meet in LDS in a fixed order
+      // the 0/1 match of every row is staged in LDS first, so that the row loop below has no
+      // dependent (index -> data) load chain: every D load is unconditional and independent
+      float *match = svec + 2048;   // rows are processed in chunks of 2048
+      for (int c0 = 0; c0 < j.emb_rows || c0 == 0; c0 += 2048) {
+        const int nrow = min(2048, j.emb_rows - c0);
+        __syncthreads();
+        for (int r = threadIdx.x; r < nrow; r += 1024)
+          match[r] = j.emb_cat[(size_t)((c0 + r) % j.emb_B) * j.emb_ld_cat + i] == rowid ? 1.f : 0.f;
+        __syncthreads();
+        if (H <= 512) {
+          const int Hp = (H + 63) & ~63, ng = 1024 / Hp;
+          const int kk = threadIdx.x % Hp, rg = threadIdx.x / Hp;
+          float sk = 0.f;
+          if (rg < ng && kk < H) {
+#pragma unroll 4
+            for (int r = rg; r < nrow; r += ng) {
+              const float d = j.emb_D[(size_t)(c0 + r) * j.emb_ldd + kk];
+              sk += match[r] != 0.f ? d : 0.f;   // select, not multiply: a NaN in another row must not leak
+            }
+          }
+          if (rg < ng) part[rg * Hp + kk] = (c0 == 0 ? 0.f : part[rg * Hp + kk]) + sk;
+        } else {
+          for (int k = threadIdx.x; k < H; k += 1024) {
+            float sk = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < nrow; ++r) {
+              const float d = j.emb_D[(size_t)(c0 + r) * j.emb_ldd + k];
+              sk += match[r] != 0.f ? d : 0.f;
+            }
+            part[k] = (c0 == 0 ? 0.f : part[k]) + sk;   // H <= 2048 here (host check)
+          }
+        }
+      }
+      __syncthreads();
       if (H <= 512) {
         const int Hp = (H + 63) & ~63, ng = 1024 / Hp;
-        const int kk = threadIdx.x % Hp, rg = threadIdx.x / Hp;
-        float sk = 0.f;
-        if (rg < ng && kk < H) {
-          for (int r = rg; r < j.emb_rows; r += ng)
-            if (j.emb_cat[(size_t)(r % j.emb_B) * j.emb_ld_cat + i] == rowid) sk += j.emb_D[(size_t)r * j.emb_ldd + kk];
-        }
-        if (rg < ng) part[rg * Hp + kk] = sk;
-        __syncthreads();
         if ((int)threadIdx.x < H) {
           float t = 0.f;
           for (int g = 0; g < ng; ++g) t += part[g * Hp + threadIdx.x];
           sfin[threadIdx.x] = t;
-        }
-      } else {
-        for (int k = threadIdx.x; k < H; k += 1024) {
-          float sk = 0.f;
-          for (int r = 0; r < j.emb_rows; ++r)
-            if (j.emb_cat[(size_t)(r % j.emb_B) * j.emb_ld_cat + i] == rowid) sk += j.emb_D[(size_t)r * j.emb_ldd + k];
-          sfin[k] = sk;
         }
       }
       __syncthreads();
@@ -891,7 +910,7 @@ extern "C" int agx_small_grads(void *stream, const agx_small_grads_t *j) {
   if (j->emb_grad) {
     AGX_CHECK_ARG(j->emb.n_cat > 0 && j->emb.n_cat <= AGX_MAX_CAT && j->emb_D && j->emb_W && j->emb_cat &&
                       j->emb_B > 0 && j->emb_rows >= 0 && j->emb_ldd >= j->emb_H && j->emb_ldw >= j->emb_H &&
-                      j->emb_ld_cat >= j->emb.n_cat && j->emb_H <= 3072, "agx_small_grads: embedding job");
+                      j->emb_ld_cat >= j->emb.n_cat && j->emb_H <= 2048, "agx_small_grads: embedding job");
     for (int i = 0; i < j->emb.n_cat; ++i) {
       blocks += j->emb.vocab[i];
     }

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
 
   // MFMAs of one staged K-tile: per 8-k group one ds_read_b128 per fragment, then 4 x TM x TN MFMAs.
   // The reads of group g+1 are issued before the MFMAs of group g (register double buffer).
-  auto mma_tile = [&](const float *cA, const float *cB) {
+  auto mma_tile = [&](const float *cA, const float *cB, auto &&after_first_group) {
     constexpr int NG = BK / 8;
     float4 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -367,8 +367,13 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
           }
       __builtin_amdgcn_sched_barrier(0);
+      if (g == 0) {
+        after_first_group();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
+  auto nothing = [] {};
 
   int t = 0;
   if (VEC && DBG == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
@@ -377,15 +382,28 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
     int offa[TileA::PT], offb[TileB::PT];
     TileA::lane_offsets(p.lda, tid, offa);
     TileB::lane_offsets(p.ldb, tid, offb);
+    // Staging pipeline: the registers always hold the tile AFTER the one being multiplied.  Inside
+    // iteration t, right after the first MFMA group, tile t+1 goes from the registers into the other
+    // LDS buffer (free since the barrier that ended iteration t-1) and the loads of tile t+2 are
+    // issued into the same registers: every global load has a whole iteration to land, and the
+    // store / load instructions issue between MFMA groups instead of in front of the barrier.
+    if (nfull > 1) {
+      TileA::load_fast(TileA::ubase(p.A, p.lda, m0, kbeg + BK), offa, ra);
+      TileB::load_fast(TileB::ubase(p.B, p.ldb, n0, kbeg + BK), offb, rb);
+    }
     for (; t + 1 < nfull; ++t) {
       const float *cA = smem + (t & 1) * STAGE;
-      const int k0 = kbeg + (t + 1) * BK;
-      TileA::load_fast(TileA::ubase(p.A, p.lda, m0, k0), offa, ra);
-      TileB::load_fast(TileB::ubase(p.B, p.ldb, n0, k0), offb, rb);
-      mma_tile(cA, cA + TileA::LDS_FLOATS);
       float *nA = smem + ((t + 1) & 1) * STAGE;
-      TileA::store_fast(nA, tid, ra);
-      TileB::store_fast(nA + TileA::LDS_FLOATS, tid, rb);
+      const bool ahead = t + 2 < nfull;
+      const int k2 = kbeg + (t + 2) * BK;
+      mma_tile(cA, cA + TileA::LDS_FLOATS, [&] {
+        TileA::store_fast(nA, tid, ra);
+        TileB::store_fast(nA + TileA::LDS_FLOATS, tid, rb);
+        if (ahead) {
+          TileA::load_fast(TileA::ubase(p.A, p.lda, m0, k2), offa, ra);
+          TileB::load_fast(TileB::ubase(p.B, p.ldb, n0, k2), offb, rb);
+        }
+      });
       __syncthreads();
     }
   }
@@ -398,7 +416,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
       TileA::load(p.A, p.lda, m0, p.M, k0, kend, tid, ra);
       TileB::load(p.B, p.ldb, n0, p.N, k0, kend, tid, rb);
     }
-    mma_tile(cA, cB);
+    mma_tile(cA, cB, nothing);
     if (DBG >= 2) {  // timing ablation only (wrong results): no LDS refill, no barrier
       if (DBG == 2) {
 #pragma unroll
