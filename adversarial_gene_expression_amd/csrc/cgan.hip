@@ -40,7 +40,8 @@ struct agx_cgan {
   float *gp = nullptr, *gg = nullptr, *dp = nullptr, *dg = nullptr;  // flat params / grads
   // workspace views
   int Bm = 0, S = 6, G = 0, Dd = 0, Dg = 0, ldx = 0, ldg0 = 0, ncov = 0;
-  float *X = nullptr;                       // [3Bm, ldx] stacked critic input (+cov cols)
+  float *X = nullptr;                       // [3Bm, ldx] stacked critic input (+cov cols): = Xbuf[0] outside a captured iteration
+  float *Xbuf[2] = {nullptr, nullptr};      // two of them: step k+1's fake rows are assembled beside step k's tail
   float *A[AGX_MAX_LAYERS + 1] = {};        // critic activations  [3Bm, ldh]
   float *D[AGX_MAX_LAYERS + 1] = {};        // critic deltas       [3Bm, ldh]
   int ldh[AGX_MAX_LAYERS + 1] = {};
@@ -53,7 +54,7 @@ struct agx_cgan {
   float *F = nullptr;                       // [S*Bm, ldsx] fake rows of a whole captured iteration
   int ldgh[AGX_MAX_LAYERS + 1] = {};
   // staging for the captured iteration (agx_cgan_iter_*)
-  float *sx = nullptr, *snum = nullptr, *zbuf = nullptr, *abuf = nullptr, *losslog = nullptr;
+  float *snum = nullptr, *zbuf = nullptr, *abuf = nullptr, *losslog = nullptr;
   int32_t *scat = nullptr;
   uint64_t *rngpos = nullptr;
   int ldsx = 0;
@@ -115,7 +116,9 @@ void carve(agx_cgan *h, float *base) {
   const agx_cgan_config_t &c = h->cfg;
   const int Bm = c.max_batch, S = h->S;
   Carver cv(base);
-  h->X = cv.take((int64_t)3 * Bm * h->ldx);
+  h->Xbuf[0] = cv.take((int64_t)3 * Bm * h->ldx);
+  h->Xbuf[1] = cv.take((int64_t)3 * Bm * h->ldx);
+  h->X = h->Xbuf[0];
   const int L = c.disc.n_layers - 1;
   for (int l = 1; l <= L; ++l) {
     h->ldh[l] = r4(c.disc.dims[l]);
@@ -136,7 +139,6 @@ void carve(agx_cgan *h, float *base) {
   }
   h->ldsx = r4(c.x_dim);
   h->F = cv.take((int64_t)S * Bm * h->ldsx);
-  h->sx = cv.take((int64_t)Bm * h->ldsx);
   h->snum = cv.take((int64_t)Bm * std::max(c.gen.n_num, 1));
   h->scat = reinterpret_cast<int32_t *>(cv.take((int64_t)Bm * std::max(c.gen.emb.n_cat, 1)));
   h->zbuf = cv.take((int64_t)S * Bm * c.z_dim);
@@ -618,32 +620,54 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     AGX_TRY(flush());
   }
   *draws = (int64_t)sub;
+  // Large batches use two stacked-input buffers alternately: while step k works on one, a side
+  // stream assembles step k+1's fake rows (a 2*B*G*4-byte copy) in the other, beside step k's kernels.
+  const bool dbl = B >= 128 && !agx_prof_enabled();
+  float *Xb[2] = {h->Xbuf[0], dbl ? h->Xbuf[1] : h->Xbuf[0]};
+  struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; } } restore{h};
+  // fake rows of step k (k == nbc: the generator step's rows [0,B)) into buffer k&1; with_cov: also
+  // the covariate columns of the step's rows from the CURRENT embedding tables (same launch)
+  auto place_fake = [&](int k, hipStream_t s, bool with_cov = false) -> int {
+    const bool gstep = (k == nbc);
+    return agx_stack_rows(s, &dm.emb, h->dp, h->F + (size_t)k * B * h->ldsx, h->ldsx, gstep ? 0 : B, B, h->snum,
+                          dm.n_num, dm.n_num, h->scat, dm.emb.n_cat, B, with_cov ? (gstep ? B : 2 * B) : 0, G,
+                          Xb[k & 1], h->ldx,
+                          gstep ? a->aug_mask_gen : a->aug_mask_disc, gstep ? a->aug_noise_gen : a->aug_noise_fake,
+                          gstep ? G : 0);
+  };
   if (in_seg(0)) {
     // ONE generator forward for all nb_critic+1 z batches (generator weights are constant until the
     // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
     AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
     AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx));
-    // real rows stay in X[0:B] for all critic steps (augmentation noise is a trace constant, :210)
-    AGX_HIP(hipMemcpy2DAsync(h->X, (size_t)h->ldx * 4, h->sx, (size_t)h->ldsx * 4, (size_t)G * 4, B,
-                             hipMemcpyDeviceToDevice, st));
-    if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, h->X, h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
+    // real rows were staged into buffer 0 rows [0,B) (agx_cgan_iter_stage) and stay there for all
+    // critic steps (augmentation noise is a trace constant, :210); buffer 1 gets a copy
+    if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, Xb[0], h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
+    if (dbl && nbc > 1)
+      AGX_HIP(hipMemcpy2DAsync(Xb[1], (size_t)h->ldx * 4, Xb[0], (size_t)h->ldx * 4, (size_t)G * 4, B,
+                               hipMemcpyDeviceToDevice, st));
+    if (dbl) AGX_TRY(place_fake(0, st));
   }
   for (int k = 0; k < nbc; ++k) {
+    h->X = Xb[k & 1];
     if (in_seg(k)) {
-      // fake rows of this step (+ :209 noise row) into X[B:2B]; covariate columns from the CURRENT tables
-      AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)k * B * h->ldsx, h->ldsx, B, B, h->snum, dm.n_num,
-                             dm.n_num, h->scat, dm.emb.n_cat, B, 2 * B, G, h->X, h->ldx, a->aug_mask_disc,
-                             a->aug_noise_fake, 0));
+      // covariate columns of [real; fake] from the CURRENT (just updated) embedding tables
+      if (dbl) AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, 2 * B, B));
+      else AGX_TRY(place_fake(k, st, true));
+      if (dbl) {   // next step's rows on a side stream; critic_core's own fork/join of aux[1] joins it
+        AGX_TRY(fork_to(h, st, 1));
+        AGX_TRY(place_fake(k + 1, h->aux[1]));
+      }
       AGX_TRY(critic_core(h, st, h->scat, B, Bg, h->abuf + (size_t)k * B, a->gp_weight,
                           a->disc_losses ? a->disc_losses : h->losslog + 4 * k));
     }
     if (in_seg(k + 1))
       AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
   }
+  h->X = Xb[nbc & 1];
   if (in_seg(nbc)) {
-    AGX_TRY(agx_stack_rows(st, &dm.emb, h->dp, h->F + (size_t)nbc * B * h->ldsx, h->ldsx, 0, B, h->snum, dm.n_num,
-                           dm.n_num, h->scat, dm.emb.n_cat, B, B, G, h->X, h->ldx, a->aug_mask_gen,
-                           a->aug_noise_gen, G));
+    if (!dbl || nbc == 0) AGX_TRY(place_fake(nbc, st, true));
+    else AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));
     AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc));
   }
   if (in_seg(nbc + 1))
@@ -713,7 +737,8 @@ extern "C" int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const floa
   hipStream_t st = agx::as_stream(stream);
   const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
   AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_stage: covariates missing");
-  AGX_HIP(hipMemcpy2DAsync(h->sx, (size_t)h->ldsx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
+  // real rows straight into rows [0,B) of stacked-input buffer 0
+  AGX_HIP(hipMemcpy2DAsync(h->Xbuf[0], (size_t)h->ldx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
                            hipMemcpyDeviceToDevice, st));
   if (ncat) AGX_HIP(hipMemcpyAsync(h->scat, cat, (size_t)B * ncat * 4, hipMemcpyDeviceToDevice, st));
   if (nnum) AGX_HIP(hipMemcpyAsync(h->snum, num, (size_t)B * nnum * 4, hipMemcpyDeviceToDevice, st));

@@ -341,3 +341,27 @@ def test_data_parallel_shards_reproduce_the_big_batch(gpu, cuts):
         if r:   # replicas stay bit-identical to each other (same summed gradients, same update)
             for a, b in zip(discs[0].get_weights() + gens[0].get_weights(), discs[r].get_weights() + gens[r].get_weights()):
                 np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('p_aug', [0, 0.25])
+def test_large_batch_graph_paths_match_eager(gpu, p_aug):
+    """Batches >= 128 take the side-branch / double-buffered form of the captured iteration (fake rows
+    of step k+1 assembled beside step k, weight gradients on side streams): same results as the
+    eager step functions.  Ragged tail of 72 rows (< 128) switches back to the serial form."""
+    from adversarial_gene_expression_amd import tf_utils as T
+    p = make_problem(G=150, B=200, H=(32, 24), seed=71)
+    x32 = p['x'].astype(np.float32)
+    out = []
+    for use_graph in (False, True):
+        _, gen, disc = _models(p)
+        T._TRACE_CONSTS.clear()
+        np.random.seed(5)
+        T.set_seed(4321)
+        go, do = T.RMSprop(5e-4), T.RMSprop(5e-4)
+        tr = T.train(x32, p['cc'], _f32(p, 'nc'), p['Z'], 2, 128, gen, disc, lambda g: 0.0, lambda: None, gen_opt=go,
+                     disc_opt=do, verbose=False, p_aug=p_aug, use_graph=use_graph, nb_critic=3)
+        out.append((gen.get_weights(), disc.get_weights(), tr))
+    (gw0, dw0, tr0), (gw1, dw1, tr1) = out
+    for a, b in zip(gw0 + dw0, gw1 + dw1):
+        np.testing.assert_array_equal(a, b)
+    assert tr0['gen_loss'] == tr1['gen_loss'] and tr0['disc_loss'] == tr1['disc_loss']
