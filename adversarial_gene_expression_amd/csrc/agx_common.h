@@ -12,6 +12,35 @@ void set_error(const char *fmt, ...);
 int num_cus();
 int gemm_prepare_device();
 
+// Optimizer update fused into a weight-gradient GEMM epilogue (internal: captured single-GPU
+// iteration only).  w / s1 point at the element that corresponds to C[0,0] (same leading
+// dimension); rows [0, rows) of the result are consumed by the RMSprop update instead of stored.
+struct FusedOpt {
+  float *w, *s1;
+  int rows;
+  float lr, rho, eps;
+};
+int gemm_run(void *stream, const agx_gemm_t *g, const FusedOpt *fo);
+// true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused
+// epilogue, without split-K (then fused and unfused runs sum in the same order: bit-identical)
+bool gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats);
+// Loss-log snapshot done by the last small-gradient launch of a captured iteration: n floats from
+// src to the address stored at *dst_slot (left there by iter_stage; NULL address: no copy).
+struct LossCopy {
+  float *const *dst_slot;
+  const float *src;
+  int n;
+};
+int small_grads_run(void *stream, const agx_small_grads_t *j, const LossCopy &lc);
+// Everything a replayed iteration needs staged, in ONE launch: B real rows into the stacked critic
+// input, covariates into their staging buffers, RNG position and loss-snapshot address.
+int iter_stage(void *stream, const float *x, int ldxs, float *X, int ldx, int G, int B, const int32_t *cat,
+               int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
+               uint64_t rng_offset, float **loss_slot, float *losses_out);
+// RMSprop over [0, n) minus the hole [hole_lo, hole_hi) (multiples of 4) that fused epilogues updated
+int opt_rmsprop_hole(void *stream, float *w, const float *g, float *rms, int64_t n, int64_t hole_lo,
+                     int64_t hole_hi, float lr, float rho, float eps);
+
 // In-stream event bracket around the launches of one kernel class (see agx_prof_* in agx.h).
 // Inactive (two loads, no HIP call) unless profiling is enabled for the class.
 struct ProfScope {

@@ -57,6 +57,7 @@ struct agx_cgan {
   float *snum = nullptr, *zbuf = nullptr, *abuf = nullptr, *losslog = nullptr;
   int32_t *scat = nullptr;
   uint64_t *rngpos = nullptr;
+  float **loss_slot = nullptr;              // device word: where the last step snapshots the loss log
   int ldsx = 0;
   float *skws = nullptr;                    // split-K scratch
   int64_t skws_floats = 0;
@@ -145,6 +146,7 @@ void carve(agx_cgan *h, float *base) {
   h->abuf = cv.take((int64_t)S * Bm);
   h->losslog = cv.take(4 * 64);
   h->rngpos = reinterpret_cast<uint64_t *>(cv.take(16));
+  h->loss_slot = h->rngpos ? reinterpret_cast<float **>(h->rngpos + 1) : nullptr;
   // split-K scratch: the largest request over the GEMM shapes of both steps
   int64_t need = 0;
   const int Bs[2] = {Bm, std::min(Bm, 32)};
@@ -205,7 +207,9 @@ struct Gemm {  // GEMM call builder
   Gemm &aux_ws(agx_cgan *h) { g.ws = h->skws_aux; g.ws_floats = h->skws_aux_floats; return *this; }
   Gemm &interp(int rows, const float *alpha) { g.interp_rows = rows; g.interp_alpha = alpha; return *this; }
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
-  int run(hipStream_t st) { return agx_gemm_f32(st, &g); }
+  Gemm &opt(const agx::FusedOpt *f) { fo = f; return *this; }
+  const agx::FusedOpt *fo = nullptr;
+  int run(hipStream_t st) { return agx::gemm_run(st, &g, fo); }
 };
 
 int ensure_side_streams(agx_cgan *h) {
@@ -297,7 +301,7 @@ int disc_backward_chain(agx_cgan *h, hipStream_t st, int R) {
 
 // Critic gradients given X rows [0,2B) = [real; fake] (gene + covariate columns in place).
 int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_global, const float *alpha,
-                float gp_weight, float *losses) {
+                float gp_weight, float *losses, const agx::FusedOpt *fo = nullptr) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   const int L = m.n_layers - 1, R = 3 * B, G = h->G, ldx = h->ldx;
   const float invb = 1.0f / (float)B_global;
@@ -350,6 +354,10 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     Gemm g(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l], m.dims[l],
            m.dims[l + 1], R);
     g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID);
+    // layer 1 in a captured iteration: rows [0,G) of W_1 are updated in the epilogue.  Safe: every
+    // reader of those rows (forward, input gradient, second-order product) precedes this launch in
+    // stream order, and the side branches read only the covariate rows (>= G) and the deltas
+    if (l == 0) g.opt(fo);
     if (l > 0 && side) g.aux_ws(h);
     AGX_TRY(g.run(l == 0 ? st : s_hid));
   }
@@ -383,7 +391,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
 // Generator gradients given X rows [0,B) = generated rows (+covariates) and the generator
 // activations of those rows at row offset gen_row0 of gin0 / gh[].
 int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_global, int gen_row0,
-             float *losses) {
+             float *losses, const agx::FusedOpt *fo = nullptr, const agx::LossCopy *lc = nullptr) {
   const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
   const int Lg = gm.n_layers - 1, G = h->G, ldx = h->ldx;
   const float invb = 1.0f / (float)B_global;
@@ -403,12 +411,19 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   for (int l = Lg; l >= 0; --l) {
     const float *in = l == 0 ? h->gin0 + (size_t)gen_row0 * h->ldg0 : h->gh[l] + (size_t)gen_row0 * h->ldgh[l];
     const int ldin = l == 0 ? h->ldg0 : h->ldgh[l];
-    if (side) AGX_TRY(fork_to(h, st, 0));
-    {
+    // output layer in a captured iteration: W_out is updated in the epilogue of its gradient product,
+    // which must then follow the delta product that still reads W_out (same stream, after it)
+    const bool fused = fo && l == Lg;
+    auto weight_grad = [&](hipStream_t s, bool on_side) -> int {
       Gemm g(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l], gm.dims[l + 1], B);
       g.id(l == Lg ? AGX_K_GEN_DW_OUT : AGX_K_GEN_DW_HID);
-      if (side) g.aux_ws(h);
-      AGX_TRY(g.run(side ? h->aux[0] : st));
+      if (on_side) g.aux_ws(h);
+      if (fused) g.opt(fo);
+      return g.run(s);
+    };
+    if (!fused) {
+      if (side) AGX_TRY(fork_to(h, st, 0));
+      AGX_TRY(weight_grad(side ? h->aux[0] : st, side));
     }
     j.cs_A[j.n_colsum] = dout; j.cs_lda[j.n_colsum] = lddout; j.cs_r0[j.n_colsum] = 0; j.cs_r1[j.n_colsum] = B;
     j.cs_H[j.n_colsum] = gm.dims[l + 1]; j.cs_out[j.n_colsum] = h->gg + gm.b_off[l];
@@ -418,6 +433,9 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
           gm.dims[l + 1]);
       g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
       AGX_TRY(g.run(st));
+    }
+    if (fused) AGX_TRY(weight_grad(st, false));
+    if (l > 0) {
       dout = h->gd[l];
       lddout = h->ldgh[l];
     }
@@ -429,7 +447,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   }
   j.l_losses = losses; j.l_out = h->out; j.l_n0 = B; j.l_n1 = 0; j.l_ns = 0;   // mean(-D(fake))  :253
   j.l_inv_b = invb; j.l_gp_weight = 0.f; j.l_fake_sign = 1.f;
-  AGX_TRY(agx_small_grads(st, &j));
+  AGX_TRY(agx::small_grads_run(st, &j, lc ? *lc : agx::LossCopy{nullptr, nullptr, 0}));
   if (side) AGX_TRY(join_from(h, st, 0));
   return AGX_OK;
 }
@@ -580,6 +598,7 @@ struct agx_iter_graph {
   hipGraphExec_t exec[AGX_MAX_ITER_SEGS] = {};
   int B = 0, nb_critic = 0;
   int64_t draws = 0;
+  bool snap = false;   // the last step snapshots the loss log to the address staged per launch
 };
 
 namespace {
@@ -596,6 +615,24 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const int Bg = a->B_global > 0 ? a->B_global : B, lo = a->row_lo;
   const agx_mlp_desc_t &dm = h->cfg.disc;
   auto in_seg = [&](int s) { return seg < 0 || seg == s; };
+  // One-GPU iteration (no all-reduce between gradient and update): the two big kernels' RMSprop
+  // updates happen in the epilogue of their weight-gradient products - the 18.6 MB gradient is never
+  // written or re-read - and the optimizer launch covers the rest of the flat buffer.
+  const agx_mlp_desc_t &gm0 = h->cfg.gen;
+  const int Lg0 = gm0.n_layers - 1;
+  const int64_t dhole_lo = dm.w_off[0], dhole_hi = dm.w_off[0] + (int64_t)G * dm.ldw[0];
+  const int64_t ghole_lo = gm0.w_off[Lg0], ghole_hi = gm0.w_off[Lg0] + (int64_t)gm0.dims[Lg0] * gm0.ldw[Lg0];
+  // (small batches only: from 128 rows on the weight gradients run on side streams beside the delta
+  // chain, which pays more than the saved gradient round trip - measured at 512 rows)
+  const bool fuse = seg < 0 && !a->split && B < 128 && !getenv("AGX_NO_FUSED_OPT");
+  const bool fuse_d = fuse && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
+                      agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], 3 * B, h->skws_floats);
+  const bool fuse_g = fuse && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
+                      agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], B, h->skws_floats);
+  const agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
+  const agx::FusedOpt gfo{h->gp + ghole_lo, a->gen_rms + ghole_lo, gm0.dims[Lg0], a->lr_gen, a->rho, a->eps};
+  const bool snap = seg < 0 && !a->split && !a->disc_losses && !a->gen_losses;
+  const agx::LossCopy lcopy{h->loss_slot, h->losslog, (nbc + 1) * 4};
   uint64_t sub = 0;
   {
     // every draw of the iteration in one launch (per 16 segments), at the stream positions the eager
@@ -659,19 +696,24 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
         AGX_TRY(place_fake(k + 1, h->aux[1]));
       }
       AGX_TRY(critic_core(h, st, h->scat, B, Bg, h->abuf + (size_t)k * B, a->gp_weight,
-                          a->disc_losses ? a->disc_losses : h->losslog + 4 * k));
+                          a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dfo : nullptr));
     }
-    if (in_seg(k + 1))
-      AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
+    if (in_seg(k + 1)) {
+      if (fuse_d) AGX_TRY(agx::opt_rmsprop_hole(st, h->dp, h->dg, a->disc_rms, dm.n_flat, dhole_lo, dhole_hi, a->lr_disc, a->rho, a->eps));
+      else AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
+    }
   }
   h->X = Xb[nbc & 1];
   if (in_seg(nbc)) {
     if (!dbl || nbc == 0) AGX_TRY(place_fake(nbc, st, true));
     else AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));
-    AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc));
+    AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc,
+                     fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));
   }
-  if (in_seg(nbc + 1))
-    AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
+  if (in_seg(nbc + 1)) {
+    if (fuse_g) AGX_TRY(agx::opt_rmsprop_hole(st, h->gp, h->gg, a->gen_rms, gm0.n_flat, ghole_lo, ghole_hi, a->lr_gen, a->rho, a->eps));
+    else AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
+  }
   return AGX_OK;
 }
 }  // namespace
@@ -698,6 +740,7 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   agx_iter_graph *g = new (std::nothrow) agx_iter_graph();
   AGX_CHECK_ARG(g, "agx_cgan_iter_capture: out of host memory");
   g->h = h; g->B = a->B; g->nb_critic = a->nb_critic;
+  g->snap = !a->split && !a->disc_losses && !a->gen_losses;
   const int nseg = a->split ? a->nb_critic + 2 : 1;
   for (int s = 0; s < nseg; ++s) {
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
@@ -737,12 +780,9 @@ extern "C" int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const floa
   hipStream_t st = agx::as_stream(stream);
   const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
   AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_stage: covariates missing");
-  // real rows straight into rows [0,B) of stacked-input buffer 0
-  AGX_HIP(hipMemcpy2DAsync(h->Xbuf[0], (size_t)h->ldx * 4, x, (size_t)ldx * 4, (size_t)h->G * 4, B,
-                           hipMemcpyDeviceToDevice, st));
-  if (ncat) AGX_HIP(hipMemcpyAsync(h->scat, cat, (size_t)B * ncat * 4, hipMemcpyDeviceToDevice, st));
-  if (nnum) AGX_HIP(hipMemcpyAsync(h->snum, num, (size_t)B * nnum * 4, hipMemcpyDeviceToDevice, st));
-  return agx_set_u64(st, h->rngpos, rng_offset);
+  // one launch: real rows straight into rows [0,B) of stacked-input buffer 0, covariates, RNG position
+  return agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum, B * nnum,
+                         h->rngpos, rng_offset, h->loss_slot, nullptr);
 }
 
 extern "C" int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g) { return g ? g->nseg : 0; }
@@ -756,8 +796,20 @@ extern "C" int agx_cgan_iter_launch_seg(agx_iter_graph_t *g, void *stream, int32
 extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
                                     const int32_t *cat, const float *num, uint64_t rng_offset,
                                     float *losses_out) {
-  AGX_TRY(agx_cgan_iter_stage(g, stream, x, ldx, cat, num, rng_offset));
+  AGX_CHECK_ARG(g && g->nseg > 0 && x, "agx_cgan_iter_launch: null argument");
   hipStream_t st = agx::as_stream(stream);
+  if (g->snap) {
+    agx_cgan *h = g->h;
+    AGX_CHECK_ARG(ldx >= h->G, "agx_cgan_iter_launch: ldx < x_dim");
+    const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
+    AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_launch: covariates missing");
+    // the graph's last small-gradient launch copies the loss log to losses_out (address staged here)
+    AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum,
+                            B * nnum, h->rngpos, rng_offset, h->loss_slot, losses_out));
+    for (int s = 0; s < g->nseg; ++s) AGX_HIP(hipGraphLaunch(g->exec[s], st));
+    return AGX_OK;
+  }
+  AGX_TRY(agx_cgan_iter_stage(g, stream, x, ldx, cat, num, rng_offset));
   for (int s = 0; s < g->nseg; ++s) AGX_HIP(hipGraphLaunch(g->exec[s], st));
   if (losses_out)
     AGX_HIP(hipMemcpyAsync(losses_out, g->h->losslog, (size_t)(g->nb_critic + 1) * 4 * sizeof(float),

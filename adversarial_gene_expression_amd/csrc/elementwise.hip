@@ -4,6 +4,8 @@
 // include/agx.h.
 #include "agx_common.h"
 
+#include <algorithm>
+
 namespace {
 
 using agx::wave_sum;
@@ -281,14 +283,17 @@ __global__ void __launch_bounds__(1024) colsum_kernel(const float *__restrict__ 
 __global__ void __launch_bounds__(256) rmsprop_kernel(float *__restrict__ w,
                                                       const float *__restrict__ g,
                                                       float *__restrict__ rms, long long n,
-                                                      float lr, float rho, float eps, float gs) {
+                                                      float lr, float rho, float eps, float gs,
+                                                      long long hole_lo4, long long hole_len4) {
+  // float4 indices [hole_lo4, hole_lo4 + hole_len4) are skipped (updated by a fused GEMM epilogue)
   const long long n4 = n >> 2;
   const float omr = 1.f - rho;
   float4 *w4 = reinterpret_cast<float4 *>(w);
   const float4 *g4 = reinterpret_cast<const float4 *>(g);
   float4 *r4 = reinterpret_cast<float4 *>(rms);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n4 - hole_len4;
+       j += (long long)gridDim.x * blockDim.x) {
+    const long long i = j < hole_lo4 ? j : j + hole_len4;
     float4 wv = w4[i], gv = g4[i], rv = r4[i];
 #define AGX_RMS1(c)                                  \
   {                                                  \
@@ -497,7 +502,7 @@ __device__ __forceinline__ void colsum_block(const float *__restrict__ A, int ld
   if (weighted && bias_out && blk == 0 && threadIdx.x == 0) bias_out[0] = (float)n0 * c0 + (float)n1 * c1;
 }
 
-__global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j) {
+__global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j, const agx::LossCopy lc) {
   __shared__ float red[16][64];
   __shared__ float svec[4096];   // [0,2048): partial / final column sums, [2048,4096): row match flags
   int blk = blockIdx.x;
@@ -617,6 +622,43 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
       j.l_losses[1] = gp;
       j.l_losses[2] = wl + j.l_gp_weight * gp;
       j.l_losses[3] = 0.f;
+      // last step of a captured iteration: snapshot the whole loss log (this step's row included)
+      // into the buffer whose address the stage kernel left in device memory
+      if (lc.dst_slot) {
+        float *dst = *lc.dst_slot;
+        if (dst)
+          for (int i = 0; i < lc.n; ++i) dst[i] = lc.src[i];
+      }
+    }
+  }
+}
+
+// One launch in front of a replayed iteration: real rows -> rows [0,B) of the stacked critic input,
+// covariates -> staging, RNG stream position and the loss-snapshot address -> device memory.
+__global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict__ x, int ldxs,
+                                                         float *__restrict__ X, int ldx, int G, int vec,
+                                                         const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
+                                                         const float *__restrict__ num, float *__restrict__ snum, int n_num,
+                                                         unsigned long long *rngpos, unsigned long long rng_offset,
+                                                         float **loss_slot, float *losses_out) {
+  const int b = blockIdx.y;
+  const float *s = x + (size_t)b * ldxs;
+  float *d = X + (size_t)b * ldx;
+  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const int g4 = G >> 2;
+    for (int q = t0; q < g4; q += stride)
+      reinterpret_cast<float4 *>(d)[q] = reinterpret_cast<const float4 *>(s)[q];
+    for (int g = (g4 << 2) + t0; g < G; g += stride) d[g] = s[g];
+  } else {
+    for (int g = t0; g < G; g += stride) d[g] = s[g];
+  }
+  if (blockIdx.x == 0 && b == 0) {
+    for (int i = threadIdx.x; i < n_cat; i += blockDim.x) scat[i] = cat[i];
+    for (int i = threadIdx.x; i < n_num; i += blockDim.x) snum[i] = num[i];
+    if (threadIdx.x == 0) {
+      *rngpos = rng_offset;
+      *loss_slot = losses_out;
     }
   }
 }
@@ -785,7 +827,23 @@ extern "C" int agx_opt_rmsprop(void *stream, float *w, const float *g, float *rm
   if (n == 0) return AGX_OK;
   agx::ProfScope prof(agx::as_stream(stream), AGX_K_OPT_RMSPROP, 6.0 * n, 20.0 * n);
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n / 4 + 256, 256, 2048)), dim3(256), 0,
-                     agx::as_stream(stream), w, g, rms, (long long)n, lr, rho, eps, grad_scale);
+                     agx::as_stream(stream), w, g, rms, (long long)n, lr, rho, eps, grad_scale, 0ll, 0ll);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int agx::opt_rmsprop_hole(void *stream, float *w, const float *g, float *rms, int64_t n, int64_t hole_lo,
+                          int64_t hole_hi, float lr, float rho, float eps) {
+  AGX_CHECK_ARG(w && g && rms && n >= 0, "opt_rmsprop_hole: bad argument");
+  AGX_CHECK_ARG(hole_lo >= 0 && hole_lo <= hole_hi && hole_hi <= (n & ~(int64_t)3) && hole_lo % 4 == 0 && hole_hi % 4 == 0,
+                "opt_rmsprop_hole: hole [%lld, %lld) must be 4-aligned inside [0, %lld)", (long long)hole_lo,
+                (long long)hole_hi, (long long)n);
+  const int64_t rest = n - (hole_hi - hole_lo);
+  if (rest == 0) return AGX_OK;
+  agx::ProfScope prof(agx::as_stream(stream), AGX_K_OPT_RMSPROP, 6.0 * rest, 20.0 * rest);
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(rest / 4 + 256, 256, 2048)), dim3(256), 0,
+                     agx::as_stream(stream), w, g, rms, (long long)n, lr, rho, eps, 1.f, (long long)(hole_lo / 4),
+                     (long long)((hole_hi - hole_lo) / 4));
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
@@ -896,6 +954,10 @@ extern "C" int agx_stack_rows(void *stream, const agx_embed_t *e, const float *t
 }
 
 extern "C" int agx_small_grads(void *stream, const agx_small_grads_t *j) {
+  return agx::small_grads_run(stream, j, agx::LossCopy{nullptr, nullptr, 0});
+}
+
+int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::LossCopy &lc) {
   AGX_CHECK_ARG(j && j->n_colsum >= 0 && j->n_colsum <= AGX_MAX_LAYERS, "agx_small_grads: bad job list");
   int blocks = 0;
   for (int c = 0; c < j->n_colsum; ++c) {
@@ -920,7 +982,20 @@ extern "C" int agx_small_grads(void *stream, const agx_small_grads_t *j) {
     blocks += 1;
   }
   if (blocks == 0) return AGX_OK;
-  hipLaunchKernelGGL(small_grads_kernel, dim3(blocks), dim3(1024), 0, agx::as_stream(stream), *j);
+  AGX_CHECK_ARG(!lc.dst_slot || (j->l_losses && lc.src && lc.n >= 0), "agx_small_grads: loss snapshot without a loss job");
+  hipLaunchKernelGGL(small_grads_kernel, dim3(blocks), dim3(1024), 0, agx::as_stream(stream), *j, lc);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int agx::iter_stage(void *stream, const float *x, int ldxs, float *X, int ldx, int G, int B, const int32_t *cat,
+                    int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
+                    uint64_t rng_offset, float **loss_slot, float *losses_out) {
+  const int vec = agx::aligned16(x) && agx::aligned16(X) && ldxs % 4 == 0 && ldx % 4 == 0;
+  const int gx = std::max(1, std::min(8, agx::cdiv(G, 4 * 256)));
+  hipLaunchKernelGGL(iter_stage_kernel, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, ldx, G, vec,
+                     cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
+                     (unsigned long long)rng_offset, loss_slot, losses_out);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

@@ -45,10 +45,24 @@ struct KParams {
   int to_ws;              // 1: the main kernel stores raw partial slabs (also when splitk == 1)
   int interp_rows;        // R > 0: M == 2R rows are [real; fake]; the reduce emits rows [2R,3R) too
   const float *interp_alpha;
+  // fused optimizer (captured single-GPU iteration, OPT instantiations only): rows [0, opt_rows) of
+  // the result are a weight gradient that is consumed on the spot - RMSprop update of opt_w / opt_s1
+  // at the same offsets as C, same expression order as rmsprop_kernel, so the weights are
+  // bit-identical to gradient store + optimizer launch; the gradient of those rows is not stored
+  float *opt_w, *opt_s1;
+  int opt_rows;
+  float opt_lr, opt_rho, opt_eps;
   // SYRK only
   long long tile_begin;
   int tiles_1d;
 };
+
+__device__ __forceinline__ void opt_rmsprop_apply(const KParams &p, size_t off, float g, float w, float r) {
+  const float omr = 1.f - p.opt_rho;
+  r = p.opt_rho * r + omr * (g * g);
+  p.opt_s1[off] = r;
+  p.opt_w[off] = w - p.opt_lr * g / (sqrtf(r) + p.opt_eps);
+}
 
 __device__ __forceinline__ float epilogue_store(const KParams &p, int row, int col, float v) {
   v *= p.alpha;
@@ -69,7 +83,7 @@ __device__ __forceinline__ float epilogue_store(const KParams &p, int row, int c
 // Same epilogue for NV values of ONE column: all side loads (bias, addrow, mask, old C) are issued
 // up front with clamped (always valid) indices, so they overlap instead of one round trip each.
 // Returns the stored values in v (0 for elements outside the matrix).
-template <int NV>
+template <int NV, bool OPT = false>
 __device__ __forceinline__ void epilogue_column(const KParams &p, const int (&rows)[NV], int col,
                                                 float (&v)[NV]) {
   const int cc = min(col, p.N - 1);
@@ -94,6 +108,30 @@ __device__ __forceinline__ void epilogue_column(const KParams &p, const int (&ro
   if (p.accumulate) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) old[e] = p.C[(size_t)cr[e] * p.ldc + cc];
+  }
+  if (OPT) {
+    // plain weight gradient (alpha only): update in groups of 4 values to bound the live registers
+#pragma unroll
+    for (int e0 = 0; e0 < NV; e0 += 4) {
+      float ow[4], os[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ow[e] = p.opt_w[(size_t)cr[e0 + e] * p.ldc + cc];
+        os[e] = p.opt_s1[(size_t)cr[e0 + e] * p.ldc + cc];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = v[e0 + e] * p.alpha;
+        const bool ok = colok && rows[e0 + e] < p.M;
+        if (ok) {
+          const size_t off = (size_t)rows[e0 + e] * p.ldc + col;
+          if (rows[e0 + e] < p.opt_rows) opt_rmsprop_apply(p, off, x, ow[e], os[e]);
+          else p.C[off] = x;
+        }
+        v[e0 + e] = ok ? x : 0.f;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int e = 0; e < NV; ++e) {
@@ -286,7 +324,8 @@ struct Tile {
 
 using agx::tri_decode;
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, int DBG = 0>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, int DBG = 0,
+          bool OPT = false>
 __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -477,6 +516,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (rows[r] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[r]) * p.N + col] = v[r];
+        } else if (OPT) {
+          epilogue_column<16, true>(p, rows, col, v);
         } else {
           epilogue_column<16>(p, rows, col, v);
           if (p.rowsq) {  // deterministic per-slab partial of sum_col v^2 (only without split-K)
@@ -884,25 +925,25 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
   return AGX_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false>
 int launch(hipStream_t st, const KParams &p, int tiles) {
   using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
-  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK>;  // LDS limit raised in agx_init
+  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT>;  // LDS limit raised in agx_init
   dim3 grid(tiles, p.splitk, 1), block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false>
 int prepare_one() {
   using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
   AGX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void *>(gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK>),
+      reinterpret_cast<const void *>(gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return AGX_OK;
 }
@@ -1022,6 +1063,11 @@ int gemm_prepare_device() {
   AGX_TRY((prepare_cfg<128, 128, 2, 2, 64>()));
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, true, true>()));
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, false, true>()));
+  // weight-gradient products with the optimizer in the epilogue (TN layout)
+  AGX_TRY((prepare_one<128, 128, 2, 2, true, false, true, false, 32, true>()));
+  AGX_TRY((prepare_one<128, 128, 2, 2, true, false, false, false, 32, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true>()));
   return AGX_OK;
 }
 }  // namespace agx
@@ -1031,7 +1077,14 @@ extern "C" int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K) {
   return pl.splitk > 1 ? (int64_t)pl.splitk * M * N : 0;
 }
 
-extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
+extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) { return agx::gemm_run(stream, g, nullptr); }
+
+bool agx::gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats) {
+  const Plan pl = make_plan(M, N, K, -1, 0, ws_floats);
+  return (pl.cfg == 0 || pl.cfg == 1) && pl.splitk == 1;
+}
+
+int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo) {
   AGX_CHECK_ARG(g != nullptr, "agx_gemm_f32: null descriptor");
   AGX_CHECK_ARG(g->M >= 0 && g->N >= 0 && g->K >= 0, "agx_gemm_f32: negative dimension");
   if (g->M == 0 || g->N == 0) return AGX_OK;
@@ -1058,8 +1111,20 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
   p.ws = g->ws;
   AGX_CHECK_ARG(!g->rowsq || g->rowsq_ld >= agx::cdiv(g->N, 32), "agx_gemm_f32: rowsq_ld too small");
   // the row sum-of-squares side output is produced by the main kernel: no split-K with it
-  Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk,
-                      g->ws ? g->ws_floats : 0);
+  const bool opt = fo && fo->rows > 0;
+  if (opt) {
+    AGX_CHECK_ARG(fo->w && fo->s1 && g->ta && !g->tb && !g->rowsq && g->interp_rows == 0 && !g->bias && !g->addrow &&
+                      !g->act && !g->mask && !g->accumulate && !g->rowscale,
+                  "agx_gemm_f32: the fused optimizer takes a plain TN weight-gradient product");
+    p.opt_w = fo->w; p.opt_s1 = fo->s1;
+    p.opt_rows = fo->rows < g->M ? fo->rows : g->M;
+    p.opt_lr = fo->lr; p.opt_rho = fo->rho; p.opt_eps = fo->eps;
+  }
+  Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk, g->ws ? g->ws_floats : 0);
+  // the fused epilogue exists for the LDS-tiled kernels without split-K; callers ask
+  // gemm_can_fuse_opt first, so the product keeps the summation order of the unfused launch
+  AGX_CHECK_ARG(!opt || ((pl.cfg == 0 || pl.cfg == 1) && pl.splitk == 1),
+                "agx_gemm_f32: no fused-optimizer kernel for this shape (cfg %d, split-K %d)", pl.cfg, pl.splitk);
   p.splitk = pl.splitk;
   p.kchunk = pl.kchunk;
   p.to_ws = pl.splitk > 1;
@@ -1082,7 +1147,13 @@ extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) {
                       2.0 * g->M * (double)g->N * g->K,
                       4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N));
   int rc;
-  if (pl.cfg == 0)
+  if (opt && pl.cfg == 0)
+    rc = vec ? launch<128, 128, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
+             : launch<128, 128, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
+  else if (opt)
+    rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
+             : launch<64, 64, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
+  else if (pl.cfg == 0)
     rc = launch_layout<128, 128, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 1)
     rc = launch_layout<64, 64, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);

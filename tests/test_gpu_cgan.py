@@ -365,3 +365,31 @@ def test_large_batch_graph_paths_match_eager(gpu, p_aug):
     for a, b in zip(gw0 + dw0, gw1 + dw1):
         np.testing.assert_array_equal(a, b)
     assert tr0['gen_loss'] == tr1['gen_loss'] and tr0['disc_loss'] == tr1['disc_loss']
+
+
+def test_fused_optimizer_iteration_is_bit_identical_to_eager(gpu):
+    """At batch < 128 the captured one-GPU iteration applies RMSprop in the epilogue of the two big
+    weight-gradient products (critic W_1[:G], generator W_out) and never stores those gradients.  At
+    these sizes (wide enough for the LDS-tiled kernels that carry the fused epilogue) the weights,
+    optimizer slots and losses must still equal the eager gradient -> all-of-RMSprop sequence bit for bit."""
+    from adversarial_gene_expression_amd import tf_utils as T
+    p = make_problem(G=4297, B=44, H=(256, 192), V=(6, 8, 5), Z=10, seed=91)
+    x32 = p['x'].astype(np.float32)
+    out = []
+    for use_graph in (False, True):
+        _, gen, disc = _models(p)
+        T._TRACE_CONSTS.clear()
+        np.random.seed(5)
+        T.set_seed(77)
+        go, do = T.RMSprop(5e-4), T.RMSprop(5e-4)
+        tr = T.train(x32, p['cc'], _f32(p, 'nc'), p['Z'], 2, 32, gen, disc, lambda g: 0.0, lambda: None, gen_opt=go,
+                     disc_opt=do, verbose=False, use_graph=use_graph, nb_critic=2)
+        out.append((gen.get_weights(), disc.get_weights(), tr, do.state_arrays(disc)['rms'], go.state_arrays(gen)['rms']))
+        if use_graph:   # the fused path really ran: those gradients were consumed in registers, never stored
+            nv = len(p['V'])
+            assert not np.any(disc.get_gradients()[nv][:p['G']]) and np.any(disc.get_gradients()[nv][p['G']:])
+            assert not np.any(gen.get_gradients()[nv + 4]) and np.any(gen.get_gradients()[nv + 2])
+    (gw0, dw0, tr0, rd0, rg0), (gw1, dw1, tr1, rd1, rg1) = out
+    for a, b in zip(gw0 + dw0 + rd0 + rg0, gw1 + dw1 + rd1 + rg1):
+        np.testing.assert_array_equal(a, b)
+    assert tr0['gen_loss'] == tr1['gen_loss'] and tr0['disc_loss'] == tr1['disc_loss']
