@@ -20,7 +20,31 @@ struct FusedOpt {
   int rows;
   float lr, rho, eps;
 };
-int gemm_run(void *stream, const agx_gemm_t *g, const FusedOpt *fo);
+// raw_slabs != NULL: no reduce launch; the split-K partial slabs stay in g->ws as [M][splitk][N]
+// (also when splitk == 1) and *raw_slabs receives splitk - the caller's kernel finishes the product
+int gemm_run(void *stream, const agx_gemm_t *g, const FusedOpt *fo, int *raw_slabs);
+
+// Small-batch critic tail (two hidden layers of width <= 256): everything between the split-K slabs
+// of the first-layer product and the next big product in ONE launch per phase instead of 3 + 3.
+struct TailArgs {
+  const float *ws; int splitk; int m_slab;      // slabs [m_slab][splitk][H1]
+  int H1, H2;
+  const float *W2; int ldw2;
+  float slope;
+  float *A1; int lda1; float *A2; int lda2;
+  // mode 0 (forward): rows_out = interp ? 3*interp_rows : m_slab
+  const float *b1, *b2, *w3, *b3, *alpha;
+  int interp_rows;
+  float *D2; int ldd2; float *out;
+  int n0, n1; float c0, c1, c2;
+  // mode 1 (gradient-penalty second order on rows [row0, row0 + m_slab) of A1 / A2 / D1)
+  int row0;
+  const float *rowsq; int rowsq_ld, nslab;
+  float *slopes, *fscale, *D1; int ldd1;
+  float *xcov; int ldx, ncov;
+  float coef;
+};
+int critic_tail(void *stream, int mode, const TailArgs &a);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused
 // epilogue, without split-K (then fused and unfused runs sum in the same order: bit-identical)
 bool gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats);

@@ -209,7 +209,8 @@ struct Gemm {  // GEMM call builder
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
   Gemm &opt(const agx::FusedOpt *f) { fo = f; return *this; }
   const agx::FusedOpt *fo = nullptr;
-  int run(hipStream_t st) { return agx::gemm_run(st, &g, fo); }
+  int run(hipStream_t st) { return agx::gemm_run(st, &g, fo, nullptr); }
+  int run_slabs(hipStream_t st, int *splitk) { return agx::gemm_run(st, &g, nullptr, splitk); }
 };
 
 int ensure_side_streams(agx_cgan *h) {
@@ -261,12 +262,49 @@ int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo) {
   return AGX_OK;
 }
 
+// Small batches of the two-hidden-layer critic (the reference shape): the launches between the
+// first-layer slabs and the next big product are one workgroup-per-row-group kernel (tail.hip)
+bool tail_ok(const agx_cgan *h, int rows) {
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  static const bool off = getenv("AGX_NO_TAIL") != nullptr;
+  return !off && m.n_layers == 3 && m.dims[1] <= 256 && m.dims[2] <= 256 && rows <= 64;
+}
+
+agx::TailArgs tail_args(agx_cgan *h, int splitk, int m_slab) {
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  agx::TailArgs t;
+  memset(&t, 0, sizeof(t));
+  t.ws = h->skws; t.splitk = splitk; t.m_slab = m_slab;
+  t.H1 = m.dims[1]; t.H2 = m.dims[2];
+  t.W2 = h->dp + m.w_off[1]; t.ldw2 = m.ldw[1];
+  t.slope = h->cfg.slope;
+  t.A1 = h->A[1]; t.lda1 = h->ldh[1]; t.A2 = h->A[2]; t.lda2 = h->ldh[2];
+  return t;
+}
+
+int tail_forward(agx_cgan *h, hipStream_t st, int splitk, int m_slab, int interp_rows, const float *alpha, int n0,
+                 int n1, float c0, float c1, float c2) {
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  agx::TailArgs t = tail_args(h, splitk, m_slab);
+  t.b1 = h->dp + m.b_off[0]; t.b2 = h->dp + m.b_off[1]; t.w3 = h->dp + m.w_off[2]; t.b3 = h->dp + m.b_off[2];
+  t.alpha = alpha; t.interp_rows = interp_rows;
+  t.D2 = h->D[2]; t.ldd2 = h->ldh[2]; t.out = h->out;
+  t.n0 = n0; t.n1 = n1; t.c0 = c0; t.c1 = c1; t.c2 = c2;
+  return agx::critic_tail(st, 0, t);
+}
+
 // critic Dense stack from layer index l0 over R rows (input of layer l0 already in place),
 // then Dense(1) + seed of the backward chain D[L] = act'(A_L) * c(r) * w_out
 int disc_layers_from(agx_cgan *h, hipStream_t st, int l0, int R, int n0, int n1, float c0, float c1,
                      float c2) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   const int L = m.n_layers - 1;
+  if (l0 == 0 && tail_ok(h, R)) {
+    int sk = 0;
+    Gemm g(h, h->X, h->ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], R, m.dims[1], m.dims[0]);
+    AGX_TRY(g.id(AGX_K_DISC_FWD_IN).run_slabs(st, &sk));
+    return tail_forward(h, st, sk, R, 0, nullptr, n0, n1, c0, c1, c2);
+  }
   for (int l = l0; l < L; ++l) {
     const float *in = l == 0 ? h->X : h->A[l];
     const int ldin = l == 0 ? h->ldx : h->ldh[l];
@@ -306,11 +344,21 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   const int L = m.n_layers - 1, R = 3 * B, G = h->G, ldx = h->ldx;
   const float invb = 1.0f / (float)B_global;
   float *Xi = h->X + (size_t)2 * B * ldx;
-  // layer 1 on [real; fake]; the reduce emits the interpolated rows by linearity (:162-167, :213-214)
-  AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], 2 * B, m.dims[1],
-               m.dims[0]).bias(h->dp + m.b_off[0]).act().interp(B, alpha).id(AGX_K_DISC_FWD_IN).run(st));
-  // deeper layers + Dense(1) on the 3B stacked rows, seed c = [-1/B | +1/B | 1]
-  AGX_TRY(disc_layers_from(h, st, 1, R, B, B, -invb, invb, 1.f));
+  const bool tail = tail_ok(h, B);
+  if (tail) {
+    // layer-1 slabs of [real; fake]; one launch finishes them (interpolated rows by linearity), runs
+    // the second hidden layer and Dense(1) on the 3B rows and seeds the backward chain
+    int sk = 0;
+    AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], 2 * B, m.dims[1],
+                 m.dims[0]).id(AGX_K_DISC_FWD_IN).run_slabs(st, &sk));
+    AGX_TRY(tail_forward(h, st, sk, 2 * B, B, alpha, B, B, -invb, invb, 1.f));
+  } else {
+    // layer 1 on [real; fake]; the reduce emits the interpolated rows by linearity (:162-167, :213-214)
+    AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], 2 * B, m.dims[1],
+                 m.dims[0]).bias(h->dp + m.b_off[0]).act().interp(B, alpha).id(AGX_K_DISC_FWD_IN).run(st));
+    // deeper layers + Dense(1) on the 3B stacked rows, seed c = [-1/B | +1/B | 1]
+    AGX_TRY(disc_layers_from(h, st, 1, R, B, B, -invb, invb, 1.f));
+  }
   AGX_TRY(disc_backward_chain(h, st, R));
   // g = d_1 . W_1[:G]^T -> inter rows of X, with the per-slab row sums of squares as a side
   // output of the epilogue                                                      :168-169
@@ -319,6 +367,20 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
               .rowsq(h->rowsq, h->nslab).id(AGX_K_DISC_DX).run(st));
   // slopes; f = weight*(2/B)*(s-1)/s; D_1[inter] *= f (dg = f*g stays implicit); the penalty has
   // no gradient w.r.t. the covariate rows of W_1: zero those columns of the inter rows   :169-170
+  if (tail) {
+    // slabs of g . W_1[:G]; one launch: slopes, f, D_1[inter] *= f, e_1, e_2 (in place), covariate zeroing
+    int sk = 0;
+    float *A1i = h->A[1] + (size_t)2 * B * h->ldh[1];
+    AGX_TRY(Gemm(h, Xi, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, A1i, h->ldh[1], B, m.dims[1], G)
+                .id(AGX_K_GP2_IN).run_slabs(st, &sk));
+    agx::TailArgs t = tail_args(h, sk, B);
+    t.row0 = 2 * B;
+    t.rowsq = h->rowsq; t.rowsq_ld = h->nslab; t.nslab = h->nslab;
+    t.slopes = h->slopes; t.fscale = h->fscale; t.D1 = h->D[1]; t.ldd1 = h->ldh[1];
+    t.xcov = Xi + G; t.ldx = ldx; t.ncov = h->ncov;
+    t.coef = gp_weight * 2.0f * invb;
+    AGX_TRY(agx::critic_tail(st, 1, t));
+  } else {
   AGX_TRY(agx_gp_finalize(st, h->rowsq, h->nslab, h->nslab, h->slopes, h->fscale, D1i, h->ldh[1],
                           m.dims[1], Xi + G, ldx, h->ncov, B, gp_weight * 2.0f * invb));
   // second-order chain, in place over the inter rows of the activations
@@ -335,6 +397,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
       ldin = h->ldh[l + 1];
       K = m.dims[l + 1];
     }
+  }
   }
   // kernel gradients: one stacked product per layer (K = 3B).  The big layer-1 product stays on
   // the main stream; the hidden-layer products and the small-gradient kernel run beside it.

@@ -43,6 +43,7 @@ struct KParams {
   float *ws;
   int splitk, kchunk;
   int to_ws;              // 1: the main kernel stores raw partial slabs (also when splitk == 1)
+  int ws_by_row;          // slab layout, see slab_off
   int interp_rows;        // R > 0: M == 2R rows are [real; fake]; the reduce emits rows [2R,3R) too
   const float *interp_alpha;
   // fused optimizer (captured single-GPU iteration, OPT instantiations only): rows [0, opt_rows) of
@@ -56,6 +57,13 @@ struct KParams {
   long long tile_begin;
   int tiles_1d;
 };
+
+// float offset of row `row` of split-K slab z: [z][M][N] for the library's own reduce kernels,
+// [M][z][N] (all partials of a row within splitk*N contiguous floats) when a caller's kernel
+// finishes the product
+__device__ __forceinline__ size_t slab_off(const KParams &p, int z, int row) {
+  return p.ws_by_row ? ((size_t)row * p.splitk + z) * p.N : ((size_t)z * p.M + row) * p.N;
+}
 
 __device__ __forceinline__ void opt_rmsprop_apply(const KParams &p, size_t off, float g, float w, float r) {
   const float omr = 1.f - p.opt_rho;
@@ -515,7 +523,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
         if (p.to_ws) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (rows[r] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[r]) * p.N + col] = v[r];
+            if (rows[r] < p.M && col < p.N) p.ws[slab_off(p, z, rows[r]) + col] = v[r];
         } else if (OPT) {
           epilogue_column<16, true>(p, rows, col, v);
         } else {
@@ -757,7 +765,7 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
     if (p.to_ws) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (rows[q] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[q]) * p.N + col] = v[q];
+        if (rows[q] < p.M && col < p.N) p.ws[slab_off(p, z, rows[q]) + col] = v[q];
     } else {
       epilogue_column<4>(p, rows, col, v);
       if (p.rowsq) {
@@ -866,7 +874,7 @@ __global__ void __launch_bounds__(64) gemm_wave_kernel(const KParams p) {
       if (p.to_ws) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (rows[r] < p.M && col < p.N) p.ws[((size_t)z * p.M + rows[r]) * p.N + col] = v[r];
+          if (rows[r] < p.M && col < p.N) p.ws[slab_off(p, z, rows[r]) + col] = v[r];
       } else {
         epilogue_column<16>(p, rows, col, v);
         if (p.rowsq) {
@@ -978,7 +986,8 @@ struct Plan {
 
 const int kWaveTiles[8][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {3, 1}, {1, 4}, {4, 1}, {3, 2}};
 
-Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_floats) {
+// layout: 0 NN, 1 NT, 2 TN, -1 unknown (workspace bound: the larger split of the candidates)
+Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_floats, int layout = -1) {
   Plan pl;
   const int cus = agx::num_cus();
   const int ktiles = agx::cdiv(K, BK);
@@ -997,6 +1006,10 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
       const double e128 = (double)tilesL / (double)(agx::cdiv64(tilesL, cus) * cus);
       const double e64 = (double)t64 / (double)(agx::cdiv64(t64, cus) * cus);
       if (tilesL >= cus && e128 < 0.8 && e64 > e128 + 0.12) cfg = 1;
+      // few output tiles over a long K (first critic layer at 512 rows: 1024 x 256 x 18161): the
+      // 8-wave 128x128 workgroup, ONE per CU, measured 96 us against 105 for two 4-wave ones (and
+      // 53 against 58 us at 512 x 256 x 18154); NN only (the layouts measured)
+      if (layout == 0 && tilesL <= 16 && ktiles >= 128) cfg = 5;
     }
     else
       cfg = 1;
@@ -1022,13 +1035,15 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
     } else if (cfg == 3) {
       // keep the per-block K range around 128..512 (1-2 load rounds per wave) while the grid
       // stays within a few waves of workgroups
+      // (one workgroup per CU measured best at the 18k-gene shapes: 64 x 256 x 18161 takes 13.8 us
+      // with 16 slices vs 15.8 with 32; 32 x 256 x 18154 10.6 us with 32 slices vs 12.1 with 64)
       if (K > 512) {
-        sk = std::min(agx::cdiv(K, 128), agx::cdiv(2 * cus, pl.tiles));
+        sk = std::min(agx::cdiv(K, 128), agx::cdiv(cus, pl.tiles));
         if (sk > agx::cdiv(K, 128)) sk = agx::cdiv(K, 128);
       }
     } else {
       // workgroups that can be resident at once (LDS-limited): one round of blocks, no tail round
-      const int slots = cus * (cfg == 4 ? 1 : ((cfg == 0 || cfg == 5) ? 2 : 4));
+      const int slots = cus * ((cfg == 4 || (cfg == 5 && force_cfg < 0)) ? 1 : ((cfg == 0 || cfg == 5) ? 2 : 4));
       if (pl.tiles * 2 <= slots && ktiles >= 32) {
         sk = slots / pl.tiles;                 // fill the resident slots exactly once
         if (sk > ktiles / 4) sk = ktiles / 4;  // keep >= 4 K-tiles per slice
@@ -1073,18 +1088,19 @@ int gemm_prepare_device() {
 }  // namespace agx
 
 extern "C" int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K) {
-  Plan pl = make_plan(M, N, K, -1, -1, INT64_MAX);
-  return pl.splitk > 1 ? (int64_t)pl.splitk * M * N : 0;
+  int sk = 1;
+  for (int layout = -1; layout <= 0; ++layout) sk = std::max(sk, make_plan(M, N, K, -1, -1, INT64_MAX, layout).splitk);
+  return sk > 1 ? (int64_t)sk * M * N : 0;
 }
 
-extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) { return agx::gemm_run(stream, g, nullptr); }
+extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) { return agx::gemm_run(stream, g, nullptr, nullptr); }
 
 bool agx::gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats) {
-  const Plan pl = make_plan(M, N, K, -1, 0, ws_floats);
+  const Plan pl = make_plan(M, N, K, -1, 0, ws_floats, 2);
   return (pl.cfg == 0 || pl.cfg == 1) && pl.splitk == 1;
 }
 
-int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo) {
+int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, int *raw_slabs) {
   AGX_CHECK_ARG(g != nullptr, "agx_gemm_f32: null descriptor");
   AGX_CHECK_ARG(g->M >= 0 && g->N >= 0 && g->K >= 0, "agx_gemm_f32: negative dimension");
   if (g->M == 0 || g->N == 0) return AGX_OK;
@@ -1120,7 +1136,8 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo) {
     p.opt_rows = fo->rows < g->M ? fo->rows : g->M;
     p.opt_lr = fo->lr; p.opt_rho = fo->rho; p.opt_eps = fo->eps;
   }
-  Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk, g->ws ? g->ws_floats : 0);
+  Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk, g->ws ? g->ws_floats : 0,
+                      g->ta ? 2 : (g->tb ? 1 : 0));
   // the fused epilogue exists for the LDS-tiled kernels without split-K; callers ask
   // gemm_can_fuse_opt first, so the product keeps the summation order of the unfused launch
   AGX_CHECK_ARG(!opt || ((pl.cfg == 0 || pl.cfg == 1) && pl.splitk == 1),
@@ -1128,6 +1145,17 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo) {
   p.splitk = pl.splitk;
   p.kchunk = pl.kchunk;
   p.to_ws = pl.splitk > 1;
+  if (raw_slabs) {
+    // the caller's own kernel finishes the product: leave the split-K slabs ws[z][M][N] unreduced
+    AGX_CHECK_ARG(!opt && !g->rowsq && g->interp_rows == 0, "agx_gemm_f32: raw slabs combine with nothing");
+    if (!g->ws || g->ws_floats < (int64_t)pl.splitk * g->M * g->N) {
+      agx::set_error("agx_gemm_f32: raw slabs need a workspace of splitk*M*N floats");
+      return AGX_E_WORKSPACE;
+    }
+    p.to_ws = 1;
+    p.ws_by_row = 1;
+    *raw_slabs = pl.splitk;
+  }
   if (g->interp_rows > 0) {
     // [real; fake] -> [real; fake; interpolated]: always finished by the reduce kernel
     AGX_CHECK_ARG(g->M == 2 * g->interp_rows && g->interp_alpha, "agx_gemm_f32: interp needs M == 2*interp_rows and alpha");
@@ -1187,6 +1215,7 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo) {
     else rc = launch_direct<true, false>(st, p, pl.tiles, vec, gpw);
   }
   if (rc != AGX_OK) return rc;
+  if (raw_slabs) return AGX_OK;
   if (p.interp_rows > 0) return launch_reduce<true>(st, p);
   if (p.to_ws) return launch_reduce<false>(st, p);
   return AGX_OK;

@@ -1,0 +1,184 @@
+// Small-batch critic tail (batch <= 64, two hidden layers of width <= 256): at batch 32 the hidden
+// part of the critic is a chain of tiny dependent launches (split-K reduce, Dense+ReLU, Dense(1),
+// backward seed; gradient-penalty finalisation, reduce, second-order Dense) whose cost is launch
+// latency, not work.  Rows are independent through all of them, so ONE workgroup carries up to four
+// rows from the first-layer slabs to the last value the next big product needs:
+//
+//   mode 0 (tf_utils.py:132-135, :165-167, :213-214): A1 = act(sum_z slab_z [+ interpolation by
+//           linearity] + b1); A2 = act(A1 . W2 + b2); out = A2 . w3 + b3; D2 = act'(A2) * c(row) * w3
+//   mode 1 (tf_utils.py:168-170 and its derivative): s = sqrt(sum rowsq) (no epsilon);
+//           f = coef*(s-1)/s; D1 *= f; E1 = act'(A1) * f * sum_z slab_z  (in place over A1);
+//           E2 = act'(A2) * (E1 . W2)  (in place over A2); covariate columns of the rows zeroed
+//
+// fp32 VALU (4 rows x 256 x 256 MACs per workgroup: nothing for MFMA to win); fixed summation
+// orders (deterministic).
+#include "agx_common.h"
+
+namespace {
+
+using agx::wave_sum;
+
+constexpr int TW = 256;  // max hidden width
+constexpr int TR = 4;    // rows per workgroup
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p) {
+  __shared__ float raw[TR][TW];
+  __shared__ float4 a1[TW];   // [k] -> the four rows' values: one ds_read_b128 per k in the Dense loop
+  __shared__ float part[4][TR][TW];
+  __shared__ float red[16];
+  const int t = threadIdx.x, i = t >> 8, c = t & 255, lane = t & 63, wave = t >> 6;
+  const bool interp = MODE == 0 && p.interp_rows > 0;
+  const int R = p.interp_rows;
+  // slab rows / output rows of this workgroup
+  const int r0 = interp ? (int)blockIdx.x : (int)blockIdx.x * TR;
+  const int nsl = interp ? 2 : min(TR, p.m_slab - r0);
+  const int nout = interp ? 3 : nsl;
+  auto srow = [&](int k) { return interp ? r0 + k * R : r0 + k; };
+  auto orow = [&](int k) { return interp ? r0 + k * R : p.row0 + r0 + k; };
+
+  float f = 1.f;
+  if (MODE == 1) {
+    // slopes from the per-slab partial sums of squares (same order as gp_finalize_kernel)
+    float s = 0.f;
+    if (i < nsl) {
+      const float *q = p.rowsq + (size_t)srow(i) * p.rowsq_ld;
+      for (int j = c; j < p.nslab; j += 256) s += q[j];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float sl = sqrtf(red[4 * i] + red[4 * i + 1] + red[4 * i + 2] + red[4 * i + 3]);
+    f = p.coef * (sl - 1.f) / sl;  // sl == 0 -> NaN propagates like the reference
+    if (i < nsl && c == 0) {
+      p.slopes[srow(i)] = sl;
+      p.fscale[srow(i)] = f;
+    }
+    __syncthreads();
+  }
+
+  // ---- first-layer slabs -> rows of layer-1 activations (mode 0) / second-order deltas (mode 1)
+  // (one thread per (row, column); a variant with the slabs dealt over all four thread groups and
+  // 16 loads in flight per thread measured twice as slow)
+  float v = 0.f;
+  if (i < nsl && c < p.H1) {
+    const size_t stride = (size_t)p.H1;   // slabs [row][z][H1]: a row's partials are contiguous
+    const float *s0 = p.ws + (size_t)srow(i) * p.splitk * p.H1 + c;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    int z = 0;
+    for (; z + 8 <= p.splitk; z += 8) {   // eight independent loads in flight
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = s0[(size_t)(z + u) * stride];
+      q0 += x[0]; q1 += x[1]; q2 += x[2]; q3 += x[3];
+      q0 += x[4]; q1 += x[5]; q2 += x[6]; q3 += x[7];
+    }
+    for (; z < p.splitk; ++z) q0 += s0[(size_t)z * stride];
+    v = (q0 + q1) + (q2 + q3);
+  }
+  if (MODE == 0) {
+    raw[i][c] = v;
+    __syncthreads();
+    float a = 0.f;
+    if (i < nout && c < p.H1) {
+      float x;
+      if (interp && i == 2) {
+        const float r = raw[0][c], fk = raw[1][c];
+        x = r + p.alpha[r0] * (fk - r);
+      } else {
+        x = raw[i][c];
+      }
+      x += p.b1[c];
+      a = x > 0.f ? x : x * p.slope;
+      p.A1[(size_t)orow(i) * p.lda1 + c] = a;
+    }
+    reinterpret_cast<float *>(&a1[c])[i] = a;
+  } else {
+    float e = 0.f;
+    if (i < nsl && c < p.H1) {
+      const size_t o = (size_t)orow(i) * p.lda1 + c;
+      const float x = v * f;
+      e = p.A1[o] > 0.f ? x : x * p.slope;
+      p.A1[o] = e;
+      float *d = p.D1 + (size_t)orow(i) * p.ldd1 + c;
+      *d = *d * f;
+    }
+    if (i < nsl && c < p.ncov) p.xcov[(size_t)srow(i) * p.ldx + c] = 0.f;
+    reinterpret_cast<float *>(&a1[c])[i] = e;
+  }
+  __syncthreads();
+
+  // ---- hidden Dense: k split over the four 256-thread groups, W2 rows read coalesced, once
+  {
+    const int j = c, q = i;
+    float acc[TR] = {0.f, 0.f, 0.f, 0.f};
+    if (j < p.H2) {
+      const int kq = (p.H1 + 3) >> 2;
+      const int k0 = q * kq, k1 = min(p.H1, k0 + kq);
+      const float *w = p.W2 + (size_t)k0 * p.ldw2 + j;
+#pragma unroll 8
+      for (int k = k0; k < k1; ++k) {
+        const float wv = *w;
+        w += p.ldw2;
+        const float4 av = a1[k];
+        acc[0] = fmaf(av.x, wv, acc[0]);
+        acc[1] = fmaf(av.y, wv, acc[1]);
+        acc[2] = fmaf(av.z, wv, acc[2]);
+        acc[3] = fmaf(av.w, wv, acc[3]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TR; ++r) part[q][r][j] = acc[r];
+  }
+  __syncthreads();
+  float hp = 0.f;
+  if (i < nout && c < p.H2) {
+    float x = (part[0][i][c] + part[1][i][c]) + (part[2][i][c] + part[3][i][c]);
+    const size_t o = (size_t)orow(i) * p.lda2 + c;
+    if (MODE == 0) {
+      x += p.b2[c];
+      const float a = x > 0.f ? x : x * p.slope;
+      p.A2[o] = a;
+      const int row = orow(i);
+      const float cc = row < p.n0 ? p.c0 : (row < p.n0 + p.n1 ? p.c1 : p.c2);
+      const float wv = p.w3[c], dv = cc * wv;
+      p.D2[(size_t)row * p.ldd2 + c] = a > 0.f ? dv : dv * p.slope;
+      hp = a * wv;
+    } else {
+      p.A2[o] = p.A2[o] > 0.f ? x : x * p.slope;
+    }
+  }
+  if (MODE == 0) {
+    hp = wave_sum(hp);
+    if (lane == 0) red[wave] = hp;
+    __syncthreads();
+    if (i < nout && c == 0) p.out[orow(i)] = (red[4 * i] + red[4 * i + 1]) + (red[4 * i + 2] + red[4 * i + 3]) + p.b3[0];
+  }
+}
+
+}  // namespace
+
+int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a) {
+  AGX_CHECK_ARG(a.ws && a.splitk >= 1 && a.m_slab >= 1 && a.H1 >= 1 && a.H1 <= TW && a.H2 >= 1 && a.H2 <= TW &&
+                    a.W2 && a.ldw2 >= a.H2 && a.A1 && a.A2 && a.lda1 >= a.H1 && a.lda2 >= a.H2,
+                "critic_tail: bad shapes (H1=%d H2=%d m=%d)", a.H1, a.H2, a.m_slab);
+  hipStream_t st = agx::as_stream(stream);
+  if (mode == 0) {
+    AGX_CHECK_ARG(a.b1 && a.b2 && a.w3 && a.b3 && a.D2 && a.out && a.ldd2 >= a.H2 &&
+                      (a.interp_rows == 0 || (a.alpha && a.m_slab == 2 * a.interp_rows)),
+                  "critic_tail: forward arguments");
+    agx::ProfScope prof(st, AGX_K_DISC_FWD_HID, 2.0 * (a.interp_rows ? 3 * a.interp_rows : a.m_slab) * a.H1 * (double)a.H2,
+                        4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));
+    const int blocks = a.interp_rows > 0 ? a.interp_rows : agx::cdiv(a.m_slab, TR);
+    hipLaunchKernelGGL(critic_tail_kernel<0>, dim3(blocks), dim3(1024), 0, st, a);
+  } else {
+    AGX_CHECK_ARG(a.rowsq && a.slopes && a.fscale && a.D1 && a.ldd1 >= a.H1 && a.nslab >= 1 && a.rowsq_ld >= a.nslab &&
+                      a.ncov >= 0 && a.ncov <= 256 && (a.ncov == 0 || a.xcov),
+                  "critic_tail: second-order arguments");
+    agx::ProfScope prof(st, AGX_K_GP2_HID, 2.0 * a.m_slab * a.H1 * (double)a.H2,
+                        4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));
+    hipLaunchKernelGGL(critic_tail_kernel<1>, dim3(agx::cdiv(a.m_slab, TR)), dim3(1024), 0, st, a);
+  }
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}

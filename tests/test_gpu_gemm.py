@@ -27,7 +27,7 @@ SHAPES = [(1, 1, 1), (5, 37, 16), (32, 256, 71), (33, 130, 65), (96, 64, 300), (
 
 
 @pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 0)])
-@pytest.mark.parametrize('cfg', [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize('shape', SHAPES)
 def test_gemm_layouts_configs(gpu, layout, cfg, shape):
     from adversarial_gene_expression_amd import ops
