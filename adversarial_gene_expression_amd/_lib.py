@@ -195,6 +195,7 @@ SIGNATURES = {
     'agx_cgan_iter_num_segs': (_i32, [_vp]),
     'agx_cgan_iter_launch_seg': (C.c_int, [_vp, _vp, _i32]),
     'agx_cgan_iter_rng_draws': (_i64, [_vp]),
+    'agx_cgan_iter_eager': (C.c_int, [_vp, _vp, C.POINTER(IterArgs), _vp, _i32, _vp, _vp, _u64, _vp, C.POINTER(_i64)]),
     'agx_cgan_iter_destroy': (C.c_int, [_vp]),
 }
 

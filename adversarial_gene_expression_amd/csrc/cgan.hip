@@ -685,10 +685,11 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const int Lg0 = gm0.n_layers - 1;
   const int64_t dhole_lo = dm.w_off[0], dhole_hi = dm.w_off[0] + (int64_t)G * dm.ldw[0];
   const int64_t ghole_lo = gm0.w_off[Lg0], ghole_hi = gm0.w_off[Lg0] + (int64_t)gm0.dims[Lg0] * gm0.ldw[Lg0];
-  // (small batches only: from 128 rows on the weight gradients run on side streams beside the delta
-  // chain, which pays more than the saved gradient round trip - measured at 512 rows)
   const bool fuse = seg < 0 && !a->split && B < 128 && !getenv("AGX_NO_FUSED_OPT");
-  const bool fuse_d = fuse && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
+  // from 128 rows on only the critic's product fuses (+0.7 % at 512 rows): the generator's output-layer
+  // gradient would have to leave its side stream (-2 % measured with both fused)
+  const bool fuse_big = seg < 0 && !a->split && B >= 128 && !getenv("AGX_NO_FUSED_OPT");
+  const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], 3 * B, h->skws_floats);
   const bool fuse_g = fuse && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], B, h->skws_floats);
@@ -881,6 +882,26 @@ extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const flo
 }
 
 extern "C" int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g) { return g ? g->draws : 0; }
+
+extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_args_t *a, const float *x,
+                                   int32_t ldx, const int32_t *cat, const float *num, uint64_t rng_offset,
+                                   float *losses_out, int64_t *draws_out) {
+  AGX_CHECK_ARG(h && a && x, "agx_cgan_iter_eager: null argument");
+  if (!h->bound) { agx::set_error("agx_cgan_iter_eager: not bound"); return AGX_E_STATE; }
+  AGX_CHECK_ARG(a->B > 0 && a->B <= h->Bm && ldx >= h->G, "agx_cgan_iter_eager: batch %d outside (0, %d] or ldx < x_dim", a->B, h->Bm);
+  AGX_CHECK_ARG(a->nb_critic >= 0 && a->nb_critic < h->S, "agx_cgan_iter_eager: nb_critic %d needs max_steps > %d", a->nb_critic, a->nb_critic);
+  AGX_CHECK_ARG(!a->split && a->disc_rms && a->gen_rms, "agx_cgan_iter_eager: one-GPU form only; optimizer slots required");
+  const int ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
+  AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_eager: covariates missing");
+  hipStream_t st = agx::as_stream(stream);
+  const bool snap = !a->disc_losses && !a->gen_losses;
+  AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, a->B, cat, h->scat, a->B * ncat, num, h->snum,
+                          a->B * nnum, h->rngpos, rng_offset, h->loss_slot, snap ? losses_out : nullptr));
+  int64_t draws = 0;
+  AGX_TRY(record_iteration(h, st, a, -1, &draws));
+  if (draws_out) *draws_out = draws;
+  return AGX_OK;
+}
 
 extern "C" int agx_cgan_iter_destroy(agx_iter_graph_t *g) {
   if (g) {

@@ -485,11 +485,26 @@ __device__ __forceinline__ void colsum_block(const float *__restrict__ A, int ld
   const int j = blk * 64 + tx;
   float s = 0.f;
   if (j < H) {
-    for (int r = r0 + ty; r < r1; r += 16) {
+    // four independent partial sums, four loads in flight (a single dependent chain of loads made
+    // this the longest kernel of a 512-row step: 126 us beside a 152 us product)
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    int r = r0 + ty;
+    for (; r + 48 < r1; r += 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = A[(size_t)(r + 16 * u) * lda + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ru = r + 16 * u;
+        q[u] += weighted ? v[u] * (ru < n0 ? c0 : (ru < n0 + n1 ? c1 : c2)) : v[u];
+      }
+    }
+    for (; r < r1; r += 16) {
       float v = A[(size_t)r * lda + j];
       if (weighted) v *= (r < n0 ? c0 : (r < n0 + n1 ? c1 : c2));
-      s += v;
+      q[0] += v;
     }
+    s = (q[0] + q[1]) + (q[2] + q[3]);
   }
   red[ty][tx] = s;
   __syncthreads();
@@ -553,11 +568,20 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
           const int kk = threadIdx.x % Hp, rg = threadIdx.x / Hp;
           float sk = 0.f;
           if (rg < ng && kk < H) {
-#pragma unroll 4
-            for (int r = rg; r < nrow; r += ng) {
-              const float d = j.emb_D[(size_t)(c0 + r) * j.emb_ldd + kk];
-              sk += match[r] != 0.f ? d : 0.f;   // select, not multiply: a NaN in another row must not leak
+            float q[4] = {0.f, 0.f, 0.f, 0.f};
+            int r = rg;
+            for (; r + 7 * ng < nrow; r += 8 * ng) {   // eight independent loads in flight
+              float d[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) d[u] = j.emb_D[(size_t)(c0 + r + u * ng) * j.emb_ldd + kk];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) q[u & 3] += match[r + u * ng] != 0.f ? d[u] : 0.f;
             }
+            for (; r < nrow; r += ng) {
+              const float d = j.emb_D[(size_t)(c0 + r) * j.emb_ldd + kk];
+              q[0] += match[r] != 0.f ? d : 0.f;   // select, not multiply: a NaN in another row must not leak
+            }
+            sk = (q[0] + q[1]) + (q[2] + q[3]);
           }
           if (rg < ng) part[rg * Hp + kk] = (c0 == 0 ? 0.f : part[rg * Hp + kk]) + sk;
         } else {

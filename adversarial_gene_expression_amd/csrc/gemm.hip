@@ -374,6 +374,22 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // fused optimizer with one 32x32 tile per wave: the weights and optimizer slots this lane will
+  // update are requested NOW, so their round trip hides behind the whole K loop instead of
+  // stalling the epilogue (clamped addresses; out-of-range elements are never stored)
+  constexpr bool OPT_PRE = OPT && TM == 1 && TN == 1;
+  float pw[OPT_PRE ? 16 : 1], ps[OPT_PRE ? 16 : 1];
+  if (OPT_PRE) {
+    const int cc = min(n0 + wn * 32 + l31, p.N - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = min(m0 + wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2), p.M - 1);
+      const size_t off = (size_t)rr * p.ldc + cc;
+      pw[r] = p.opt_w[off];
+      ps[r] = p.opt_s1[off];
+    }
+  }
+
   float4 ra[TileA::PT], rb[TileB::PT];
   if (nt > 0) {
     TileA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
@@ -524,6 +540,16 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (rows[r] < p.M && col < p.N) p.ws[slab_off(p, z, rows[r]) + col] = v[r];
+        } else if (OPT_PRE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float x = v[r] * p.alpha;
+            if (rows[r] < p.M && col < p.N) {
+              const size_t off = (size_t)rows[r] * p.ldc + col;
+              if (rows[r] < p.opt_rows) opt_rmsprop_apply(p, off, x, pw[r], ps[r]);
+              else p.C[off] = x;
+            }
+          }
         } else if (OPT) {
           epilogue_column<16, true>(p, rows, col, v);
         } else {
@@ -1171,9 +1197,12 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   }
   const bool vec = agx::aligned16(g->A) && agx::aligned16(g->B) && (g->lda % 4 == 0) && (g->ldb % 4 == 0);
   hipStream_t st = agx::as_stream(stream);
+  // algorithmic bytes: operands + result; a fused-optimizer product reads and writes weight and
+  // slot (16 B) per updated element instead of storing the gradient (4 B)
   agx::ProfScope prof(st, g->prof_tagged ? g->prof_id : AGX_K_GEMM_UNTAGGED,
                       2.0 * g->M * (double)g->N * g->K,
-                      4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N));
+                      4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N) +
+                          (opt ? 12.0 * (double)p.opt_rows * g->N : 0.0));
   int rc;
   if (opt && pl.cfg == 0)
     rc = vec ? launch<128, 128, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)

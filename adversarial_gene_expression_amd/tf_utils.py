@@ -483,6 +483,40 @@ class _Pair:
         self._graphs = {}
         self._keep = {}
 
+    @staticmethod
+    def _iter_args(gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, aug_d, aug_g, Bg, row_lo, split):
+        a = _lib.IterArgs()
+        a.B, a.nb_critic, a.gp_weight = B, nb_critic, gp_weight
+        a.lr_disc, a.lr_gen = disc_opt.learning_rate, gen_opt.learning_rate
+        a.rho, a.eps = disc_opt.rho, disc_opt.epsilon
+        a.disc_rms, a.gen_rms = ptr(disc_opt.slot(disc)), ptr(gen_opt.slot(gen))
+        a.seed = int(seed)
+        if aug_d is not None:
+            a.aug_mask_disc, a.aug_noise_fake, a.aug_noise_real = (ptr(aug_d['mask']), ptr(aug_d['noise_fake']),
+                                                                   ptr(aug_d['noise_real']))
+        if aug_g is not None:
+            a.aug_mask_gen, a.aug_noise_gen = ptr(aug_g['mask']), ptr(aug_g['noise'])
+        if split or Bg != B:
+            a.B_global, a.row_lo, a.split = Bg, int(row_lo), int(bool(split))
+            # loss scalars go to the slots behind the gradients, so they ride the all-reduce
+            a.disc_losses = disc.grads.data_ptr() + 4 * disc.n_flat
+            a.gen_losses = gen.grads.data_ptr() + 4 * gen.n_flat
+        return a
+
+    def iteration_eager(self, x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, gp_weight, seed, rng_offset,
+                        losses=None):
+        """The captured one-GPU iteration's launch sequence queued directly on the stream (what the in-stream
+        event brackets of agx_prof_* can time: events cannot be recorded inside a graph).  Returns the
+        number of RNG stream positions consumed."""
+        lib = _lib.load()
+        B = x.shape[0]
+        a = self._iter_args(gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, None, None, B, 0, False)
+        draws = _lib.C.c_int64(0)
+        _lib.check(lib.agx_cgan_iter_eager(self.handle, _dev.stream(), a, ptr(x), x.stride(0), ptr(cc), ptr(nc),
+                                           int(rng_offset), ptr(losses) if losses is not None else None,
+                                           _lib.C.byref(draws)), 'agx_cgan_iter_eager')
+        return int(draws.value)
+
     def iteration_graph(self, gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, aug_d=None, aug_g=None,
                         batch_global=None, row_lo=0, split=False):
         """Capture (once per key) the whole loop iteration of tf_utils.py:316-323 as a hipGraph
@@ -493,22 +527,7 @@ class _Pair:
         g = self._graphs.get(key)
         if g is None:
             lib = _lib.load()
-            a = _lib.IterArgs()
-            a.B, a.nb_critic, a.gp_weight = B, nb_critic, gp_weight
-            a.lr_disc, a.lr_gen = disc_opt.learning_rate, gen_opt.learning_rate
-            a.rho, a.eps = disc_opt.rho, disc_opt.epsilon
-            a.disc_rms, a.gen_rms = ptr(disc_opt.slot(disc)), ptr(gen_opt.slot(gen))
-            a.seed = int(seed)
-            if aug_d is not None:
-                a.aug_mask_disc, a.aug_noise_fake, a.aug_noise_real = (ptr(aug_d['mask']), ptr(aug_d['noise_fake']),
-                                                                       ptr(aug_d['noise_real']))
-            if aug_g is not None:
-                a.aug_mask_gen, a.aug_noise_gen = ptr(aug_g['mask']), ptr(aug_g['noise'])
-            if split or Bg != B:
-                a.B_global, a.row_lo, a.split = Bg, int(row_lo), int(bool(split))
-                # loss scalars go to the slots behind the gradients, so they ride the all-reduce
-                a.disc_losses = disc.grads.data_ptr() + 4 * disc.n_flat
-                a.gen_losses = gen.grads.data_ptr() + 4 * gen.n_flat
+            a = self._iter_args(gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, aug_d, aug_g, Bg, row_lo, split)
             self._keep[key] = (aug_d, aug_g)
             g = _lib.C.c_void_p()
             side = torch.cuda.Stream()          # capture needs a non-default stream

@@ -124,6 +124,12 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
     def eager_iteration(i):
         s = slice((i % nbatches) * B, (i % nbatches + 1) * B)
         xb, cb, nb = x[s], cc[s], nc[s]
+        if world == 1 and use_graph:
+            # the timed region's own launch sequence (fused epilogues, tail kernels), queued instead of replayed
+            pair = T._pair(gen, disc, B, nb_critic + 1)
+            T._rng.offset += pair.iteration_eager(xb, cb, nb, gen, disc, gopt, dopt, nb_critic, 10.0, T._rng.seed,
+                                                  T._rng.offset)
+            return
         for _ in range(nb_critic):
             T.train_disc(xb, T.random_normal((B, Z)), cb, nb, gen, disc, dopt, alpha=T.random_uniform((B,)),
                          batch_global=Bg)

@@ -183,8 +183,9 @@ int agx_colsum_weighted(void *stream, const float *A, int32_t lda, int32_t R, in
                         int32_t n0, int32_t n1, float c0, float c1, float c2, float *out,
                         float *bias_out);
 
-/* Every small gradient piece of one step in ONE launch (same arithmetic and summation order as
- * agx_colsum / agx_colsum_weighted / agx_wgan_loss; the embedding job replaces the
+/* Every small gradient piece of one step in ONE launch (same arithmetic as agx_colsum /
+ * agx_colsum_weighted / agx_wgan_loss, with its own fixed - deterministic - summation order:
+ * four interleaved partial sums per column; the embedding job replaces the
  * (delta . W_cov^T) product + agx_embed_bwd pair):
  *   cs_*   : n_colsum BiasAddGrad jobs  out[j] = sum_{r0<=r<r1} A[r,j]
  *   w_*    : Dense(1) gradient          out[j] = sum_r c(r) A[r,j], bias_out = n0*c0 + n1*c1  (w_A NULL: skip)
@@ -377,6 +378,13 @@ int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const float *x, int32
 int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g);
 int agx_cgan_iter_launch_seg(agx_iter_graph_t *g, void *stream, int32_t seg);
 int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g);
+/* The same launch sequence as the captured one-GPU iteration (fused epilogues included), queued
+ * directly on `stream` instead of replayed: what agx_prof_* brackets (events cannot be captured) and
+ * debuggers see.  With profiling enabled the side-stream branches run in line.  *draws_out (host,
+ * optional) receives the number of RNG stream positions consumed. */
+int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_args_t *a, const float *x,
+                        int32_t ldx, const int32_t *cat, const float *num, uint64_t rng_offset,
+                        float *losses_out, int64_t *draws_out);
 int agx_cgan_iter_destroy(agx_iter_graph_t *g);
 
 #ifdef __cplusplus
