@@ -18,6 +18,8 @@
 //   row-contiguous source-> image [BK][rows]
 #include "agx_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -378,6 +380,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   // update are requested NOW, so their round trip hides behind the whole K loop instead of
   // stalling the epilogue (clamped addresses; out-of-range elements are never stored)
   constexpr bool OPT_PRE = OPT && TM == 1 && TN == 1;
+  // (starting each CU's k-th workgroup k * 1.7 us late, to spread the load / multiply / update phases
+  // of this one-round grid over time, only added the delay: +4 us per launch per step of delay)
   float pw[OPT_PRE ? 16 : 1], ps[OPT_PRE ? 16 : 1];
   if (OPT_PRE) {
     const int cc = min(n0 + wn * 32 + l31, p.N - 1);
