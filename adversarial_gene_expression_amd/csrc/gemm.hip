@@ -67,6 +67,21 @@ __device__ __forceinline__ size_t slab_off(const KParams &p, int z, int row) {
   return p.ws_by_row ? ((size_t)row * p.splitk + z) * p.N : ((size_t)z * p.M + row) * p.N;
 }
 
+// Sum over each half wave (lanes 0..31 / 32..63), valid in lanes 31 and 63 only: four row_shr DPP
+// steps inside the 16-lane rows, then row_bcast:15 carries a row's total into the next row.  Five
+// VALU steps per value; the __shfl_xor butterfly costs five LDS-crossbar permutes (ds_bpermute).
+__device__ __forceinline__ float half_wave_sum_at31(float v) {
+#define AGX_DPP_ADD(CTRL, ROWS) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true))
+  AGX_DPP_ADD(0x111, 0xf);  // row_shr:1
+  AGX_DPP_ADD(0x112, 0xf);  // row_shr:2
+  AGX_DPP_ADD(0x114, 0xf);  // row_shr:4
+  AGX_DPP_ADD(0x118, 0xf);  // row_shr:8
+  AGX_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+#undef AGX_DPP_ADD
+  return v;
+}
+
 __device__ __forceinline__ void opt_rmsprop_apply(const KParams &p, size_t off, float g, float w, float r) {
   const float omr = 1.f - p.opt_rho;
   r = p.opt_rho * r + omr * (g * g);
@@ -561,10 +576,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
           if (p.rowsq) {  // deterministic per-slab partial of sum_col v^2 (only without split-K)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float q = v[r] * v[r];
-#pragma unroll
-              for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-              if (l31 == 0 && rows[r] < p.M && col < p.N)
+              const float q = half_wave_sum_at31(v[r] * v[r]);
+              if (l31 == 31 && rows[r] < p.M)   // v is 0 outside the matrix; lane 31's column names the slab
                 p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
             }
           }
@@ -649,7 +662,7 @@ int launch_reduce(hipStream_t st, const KParams &p) {
   const int64_t mn_out = (int64_t)(INTERP ? p.interp_rows : p.M) * p.N;
   const bool vec = (mn_out % 4 == 0) && agx::aligned16(p.ws) && (((int64_t)p.M * p.N) % 4 == 0);
   // small outputs: 16 phases x 16 lanes (64 outputs per block) keeps >= a few hundred blocks in flight
-  const bool many_phases = mn_out <= (int64_t)1 << 17 && p.splitk >= 8;
+  const bool many_phases = mn_out <= (int64_t)1 << 16 && p.splitk >= 8;
   const int per_block = many_phases ? 64 : 256;
   const int blocks = (int)agx::cdiv64(mn_out, per_block);
 #define AGX_RED(V, P) hipLaunchKernelGGL((splitk_reduce_kernel<V, P, INTERP>), dim3(blocks), dim3(256), 0, st, p)
@@ -801,10 +814,8 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
       if (p.rowsq) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float sq = v[q] * v[q];
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-          if (cc == 0 && rows[q] < p.M && col < p.N) p.rowsq[(size_t)rows[q] * p.rowsq_ld + (col >> 5)] = sq;
+          const float sq = half_wave_sum_at31(v[q] * v[q]);
+          if (cc == 31 && rows[q] < p.M) p.rowsq[(size_t)rows[q] * p.rowsq_ld + (col >> 5)] = sq;
         }
       }
     }
@@ -910,10 +921,8 @@ __global__ void __launch_bounds__(64) gemm_wave_kernel(const KParams p) {
         if (p.rowsq) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float q = v[r] * v[r];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-            if (i == 0 && rows[r] < p.M && col < p.N) p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
+            const float q = half_wave_sum_at31(v[r] * v[r]);
+            if (i == 31 && rows[r] < p.M) p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
           }
         }
       }
