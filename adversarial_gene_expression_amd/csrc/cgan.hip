@@ -213,6 +213,20 @@ struct Gemm {  // GEMM call builder
   int run_slabs(hipStream_t st, int *splitk) { return agx::gemm_run(st, &g, nullptr, splitk); }
 };
 
+// Batch from which independent tails of a step run on side streams / the next step's rows are
+// assembled beside the current step.  OFF by default: with the fused epilogues and the faster small
+// kernels the plain one-stream sequence measured 170.6 k samples/s at 512 rows against 165.4 k with
+// both on (every cross-queue fork/join costs 5-9 us of idle GPU).  AGX_SIDE_MIN / AGX_DBL_MIN (rows)
+// switch them back on for experiments; AGX_DBL_MIN needs AGX_SIDE_MIN <= it.
+int side_min() {
+  static const int v = getenv("AGX_SIDE_MIN") ? atoi(getenv("AGX_SIDE_MIN")) : 1 << 30;
+  return v;
+}
+int dbl_min() {
+  static const int v = getenv("AGX_DBL_MIN") ? atoi(getenv("AGX_DBL_MIN")) : 1 << 30;
+  return v;
+}
+
 int ensure_side_streams(agx_cgan *h) {
   if (h->ev_fork) return AGX_OK;
   for (int i = 0; i < 2; ++i) {
@@ -404,7 +418,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   // (not at small batches: a cross-queue dependency costs more than the few-microsecond kernels it
   // would overlap - measured 0.89 vs 0.79 ms per iteration at B = 32; event brackets time one
   // stream, so profiling keeps everything serial too)
-  const bool side = B >= 128 && !agx_prof_enabled();
+  const bool side = B >= side_min() && !agx_prof_enabled();
   if (side) {
     AGX_TRY(ensure_side_streams(h));
     AGX_TRY(fork_to(h, st, 0));
@@ -466,7 +480,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
               .id(AGX_K_DISC_DX).run(st));
   // generator backward: the delta chain stays on the main stream, every weight gradient (needs
   // only the delta just computed) runs beside it on a side stream
-  const bool side = B >= 128 && !agx_prof_enabled();
+  const bool side = B >= side_min() && !agx_prof_enabled();
   agx_small_grads_t j;
   memset(&j, 0, sizeof(j));
   const float *dout = dX;
@@ -686,12 +700,14 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const int64_t dhole_lo = dm.w_off[0], dhole_hi = dm.w_off[0] + (int64_t)G * dm.ldw[0];
   const int64_t ghole_lo = gm0.w_off[Lg0], ghole_hi = gm0.w_off[Lg0] + (int64_t)gm0.dims[Lg0] * gm0.ldw[Lg0];
   const bool fuse = seg < 0 && !a->split && B < 128 && !getenv("AGX_NO_FUSED_OPT");
-  // from 128 rows on only the critic's product fuses (+0.7 % at 512 rows): the generator's output-layer
-  // gradient would have to leave its side stream (-2 % measured with both fused)
+  // from 128 rows on the critic's product always fuses (+0.7 % at 512 rows); the generator's only while
+  // its weight gradients are not on a side stream (AGX_SIDE_MIN), or AGX_FUSE_GEN_BIG=0
   const bool fuse_big = seg < 0 && !a->split && B >= 128 && !getenv("AGX_NO_FUSED_OPT");
+  static const bool gen_big = !(getenv("AGX_FUSE_GEN_BIG") && atoi(getenv("AGX_FUSE_GEN_BIG")) == 0);
+  const bool fuse_gbig = fuse_big && gen_big && B < side_min();
   const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], 3 * B, h->skws_floats);
-  const bool fuse_g = fuse && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
+  const bool fuse_g = (fuse || fuse_gbig) && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], B, h->skws_floats);
   const agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
   const agx::FusedOpt gfo{h->gp + ghole_lo, a->gen_rms + ghole_lo, gm0.dims[Lg0], a->lr_gen, a->rho, a->eps};
@@ -723,7 +739,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   *draws = (int64_t)sub;
   // Large batches use two stacked-input buffers alternately: while step k works on one, a side
   // stream assembles step k+1's fake rows (a 2*B*G*4-byte copy) in the other, beside step k's kernels.
-  const bool dbl = B >= 128 && !agx_prof_enabled();
+  const bool dbl = B >= dbl_min() && !agx_prof_enabled();
   float *Xb[2] = {h->Xbuf[0], dbl ? h->Xbuf[1] : h->Xbuf[0]};
   struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; } } restore{h};
   // fake rows of step k (k == nbc: the generator step's rows [0,B)) into buffer k&1; with_cov: also
