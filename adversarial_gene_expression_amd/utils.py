@@ -292,3 +292,117 @@ class GammaScorer:
                 return r if self.dtype == np.float32 else np.float64(r)
         r = _r_from_sums(s, g * (g - 1) // 2)
         return r if self.dtype == np.float32 else np.float64(r)
+
+
+# ---------------------------------------------------------------------------
+# extended evaluation built on the correlation kernels (reference utils.py:827-834, 876-1105)
+#
+# The G x G correlation matrices and their condensed distance lists come from the MI355X; the
+# hierarchical clustering itself stays SciPy's (`linkage('complete')`, `cophenet`), exactly as in the
+# reference - it is sequential host work on a list the GPU has already produced.
+# ---------------------------------------------------------------------------
+
+def cosine_similarity(x, y):
+    """Reference ``utils.py:827-834`` (two short host vectors)."""
+    return np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y))
+
+
+def _host(a):
+    return a.numpy() if isinstance(a, DeviceArray) else (a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a))
+
+
+def hierarchical_clustering(data, corr_fun=pearson_correlation):
+    """SciPy complete-linkage matrix of the genes on ``1 - corr``.  Reference ``utils.py:1019-1032``."""
+    from scipy.cluster.hierarchy import linkage
+    y = 1 - _host(correlations_list(data, data, corr_fun))
+    return linkage(y, 'complete')
+
+
+def dendrogram_distance(l_matrix, condensed=True):
+    """Dendrogrammatic distance between every pair of genes (height of the merge that first joins
+    them).  The reference fills a G x G matrix with O(G^2) Python loops (``utils.py:1062-1092``); those
+    values are exactly SciPy's cophenetic distances, taken here in one call (same numbers, same
+    condensed order)."""
+    from scipy.cluster.hierarchy import cophenet
+    from scipy.spatial.distance import squareform
+    d = cophenet(np.asarray(l_matrix, np.float64))
+    return d if condensed else squareform(d)
+
+
+def compare_cophenetic(l_matrix1, l_matrix2):
+    """Pearson r between two dendrograms' distance lists.  Reference ``utils.py:1095-1105``."""
+    return pearson_correlation(dendrogram_distance(l_matrix1), dendrogram_distance(l_matrix2))
+
+
+def gamma_coefficients(expr_x, expr_z):
+    """Gamma(D^X,D^Z), Gamma(D^X,T^X), Gamma(D^Z,T^Z), Gamma(T^X,T^Z).  Reference ``utils.py:876-903``.
+    Each expression matrix is correlated ONCE on the GPU (the reference computes each Pearson matrix
+    twice: for the distance list and again inside ``hierarchical_clustering``)."""
+    from scipy.cluster.hierarchy import cophenet, linkage
+    dists_x = 1 - _host(correlations_list(expr_x, expr_x))
+    dists_z = 1 - _host(correlations_list(expr_z, expr_z))
+    gamma_dx_dz = pearson_correlation(dists_x, dists_z)
+    xl_matrix = linkage(dists_x, 'complete')
+    gamma_dx_tx, _ = cophenet(xl_matrix, dists_x)
+    zl_matrix = linkage(dists_z, 'complete')
+    gamma_dz_tz, _ = cophenet(zl_matrix, dists_z)
+    return gamma_dx_dz, gamma_dx_tx, gamma_dz_tz, compare_cophenetic(xl_matrix, zl_matrix)
+
+
+def compute_tf_tg_corrs(expr, gene_symbols, tf_tg=None, flat=True):
+    """Lists of TF-TG and TG-TG correlations per transcription factor.  Reference ``utils.py:906-941``.
+    All of them are entries of ONE G x G Pearson matrix, computed once on the GPU and indexed on the
+    host (the reference runs one small correlation per TF).  ``tf_tg``: dict TF symbol -> list of target
+    symbols; the reference's RegulonDB loader (``tf_tg_interactions``) is outside this package."""
+    if tf_tg is None:
+        raise ValueError('pass tf_tg (dict TF -> target genes); the RegulonDB file loader is not part of this package')
+    gene_symbols = np.array(gene_symbols)
+    corr = _host(pearson_correlation(expr, expr))
+    tf_tg_corr, tg_tg_corr = [], []
+    for tf, tgs in tf_tg.items():
+        tg_idxs = np.array([np.where(gene_symbols == tg)[0] for tg in tgs if tg in gene_symbols]).ravel()
+        if tf in gene_symbols and len(tg_idxs) > 0:
+            sub = corr[np.ix_(tg_idxs, tg_idxs)]
+            v = sub[np.triu_indices(len(tg_idxs), k=1)]
+            tg_tg_corr += [v[~np.isnan(v)].tolist()]          # upper_diag_list semantics (utils.py:844-849)
+            tf_idx = np.argwhere(gene_symbols == tf)[0]
+            tf_tg_corr += [corr[tf_idx[0], tg_idxs].ravel().tolist()]
+    if flat:
+        tf_tg_corr = [c for corr_l in tf_tg_corr for c in corr_l]
+        tg_tg_corr = [c for corr_l in tg_tg_corr for c in corr_l]
+    return tf_tg_corr, tg_tg_corr
+
+
+def psi_coefficient(tf_tg_x, tf_tg_z, weights_type='nb_genes'):
+    """Weighted mean cosine similarity of the TF-TG correlation vectors.  Reference ``utils.py:944-963``."""
+    weights_sum = 0
+    total_sum = 0
+    for cx, cz in zip(tf_tg_x, tf_tg_z):
+        weight = len(cx) if weights_type == 'nb_genes' else 1
+        weights_sum += weight
+        total_sum += weight * cosine_similarity(np.array(cx), np.array(cz))
+    return total_sum / weights_sum
+
+
+def phi_coefficient(tg_tg_x, tg_tg_z, weights_type='nb_genes'):
+    """Weighted mean cosine similarity of the TG-TG correlation vectors.  Reference ``utils.py:966-988``."""
+    weights_sum = 0
+    total_sum = 0
+    for cx, cz in zip(tg_tg_x, tg_tg_z):
+        if len(cx) > 0:  # a TF that regulates one gene has an empty TG-TG list
+            weight = 1
+            if weights_type == 'nb_genes':
+                weight = max(np.roots([1, 1, -2 * len(cx)]))  # number of regulated genes from the list length
+            weights_sum += weight
+            total_sum += weight * cosine_similarity(np.array(cx), np.array(cz))
+    return total_sum / weights_sum
+
+
+def compute_scores(expr_x, expr_z, gene_symbols, tf_tg=None):
+    """[S_dist, S_dend, S_sdcc, S_tftg, S_tgtg].  Reference ``utils.py:991-1012`` (``tf_tg`` as in
+    ``compute_tf_tg_corrs``)."""
+    gamma_dx_dz, gamma_dx_tx, gamma_dz_tz, gamma_tx_tz = gamma_coefficients(expr_x, expr_z)
+    r_tf_tg_corr, r_tg_tg_corr = compute_tf_tg_corrs(expr_x, gene_symbols, tf_tg, flat=False)
+    s_tf_tg_corr, s_tg_tg_corr = compute_tf_tg_corrs(expr_z, gene_symbols, tf_tg, flat=False)
+    return [gamma_dx_dz, gamma_tx_tz, (gamma_dx_tx - gamma_dz_tz) ** 2,
+            psi_coefficient(r_tf_tg_corr, s_tf_tg_corr), phi_coefficient(r_tg_tg_corr, s_tg_tg_corr)]
