@@ -19,6 +19,12 @@ struct FusedOpt {
   float *w, *s1;
   int rows;
   float lr, rho, eps;
+  // optional: the same launch also runs the flat RMSprop over the rest of the network's parameter
+  // buffer - [0, rest_n) minus [rest_hole_lo, rest_hole_hi) - in workgroups behind the product's tiles.
+  // The gradients of that range must be complete BEFORE the launch (earlier launches on the stream).
+  float *rest_w = nullptr, *rest_s1 = nullptr;
+  const float *rest_g = nullptr;
+  int64_t rest_n = 0, rest_hole_lo = 0, rest_hole_hi = 0;
 };
 // raw_slabs != NULL: no reduce launch; the split-K partial slabs stay in g->ws as [M][splitk][N]
 // (also when splitk == 1) and *raw_slabs receives splitk - the caller's kernel finishes the product

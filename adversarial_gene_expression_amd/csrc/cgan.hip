@@ -425,19 +425,25 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     AGX_TRY(fork_to(h, st, 1));
   }
   hipStream_t s_hid = side ? h->aux[0] : st, s_small = side ? h->aux[1] : st;
-  for (int l = L - 1; l >= 0; --l) {
+  // With the flat update appended to the layer-1 product (fo->rest_n), that launch must come LAST:
+  // it overwrites the covariate rows of W_1 the embedding gradient reads and needs every other
+  // gradient of the step complete.
+  const bool dw1_last = fo && fo->rest_n > 0;
+  auto weight_grad = [&](int l) -> int {
     const float *in = l == 0 ? h->X : h->A[l];
     const int ldin = l == 0 ? ldx : h->ldh[l];
     Gemm g(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l], m.dims[l],
            m.dims[l + 1], R);
     g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID);
-    // layer 1 in a captured iteration: rows [0,G) of W_1 are updated in the epilogue.  Safe: every
-    // reader of those rows (forward, input gradient, second-order product) precedes this launch in
-    // stream order, and the side branches read only the covariate rows (>= G) and the deltas
+    // layer 1 in a captured iteration: rows [0,G) of W_1 (all rows with dw1_last) are updated in the
+    // epilogue.  Safe: every reader of those rows (forward, input gradient, second-order product)
+    // precedes this launch in stream order, and the side branches read only the covariate rows
+    // (>= G) and the deltas
     if (l == 0) g.opt(fo);
     if (l > 0 && side) g.aux_ws(h);
-    AGX_TRY(g.run(l == 0 ? st : s_hid));
-  }
+    return g.run(l == 0 ? st : s_hid);
+  };
+  for (int l = L - 1; l >= (dw1_last ? 1 : 0); --l) AGX_TRY(weight_grad(l));
   // everything small in one launch: bias gradients (rows 0..2B), Dense(1) gradient, embedding
   // tables (from D_1 rows 0..2B and the covariate rows of W_1), loss scalars      :174-181, :217-218
   agx_small_grads_t j;
@@ -458,6 +464,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   j.l_losses = losses; j.l_out = h->out; j.l_slopes = h->slopes; j.l_n0 = B; j.l_n1 = B; j.l_ns = B;
   j.l_inv_b = invb; j.l_gp_weight = gp_weight; j.l_fake_sign = 1.f;
   AGX_TRY(agx_small_grads(s_small, &j));
+  if (dw1_last) AGX_TRY(weight_grad(0));
   if (side) {
     AGX_TRY(join_from(h, st, 0));
     AGX_TRY(join_from(h, st, 1));
@@ -511,7 +518,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
       g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
       AGX_TRY(g.run(st));
     }
-    if (fused) AGX_TRY(weight_grad(st, false));
+    if (fused && !(fo->rest_n > 0)) AGX_TRY(weight_grad(st, false));
     if (l > 0) {
       dout = h->gd[l];
       lddout = h->ldgh[l];
@@ -526,6 +533,13 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   j.l_inv_b = invb; j.l_gp_weight = 0.f; j.l_fake_sign = 1.f;
   AGX_TRY(agx::small_grads_run(st, &j, lc ? *lc : agx::LossCopy{nullptr, nullptr, 0}));
   if (side) AGX_TRY(join_from(h, st, 0));
+  if (fo && fo->rest_n > 0) {
+    // output-layer product LAST: its launch also runs the flat update of every other generator
+    // parameter, whose gradients the launches above have completed
+    Gemm g(h, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], 1, dX, ldx, 0, h->gg + gm.w_off[Lg], gm.ldw[Lg],
+           gm.dims[Lg], gm.dims[Lg + 1], B);
+    AGX_TRY(g.id(AGX_K_GEN_DW_OUT).opt(fo).run(st));
+  }
   return AGX_OK;
 }
 
@@ -709,8 +723,22 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
                       agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], 3 * B, h->skws_floats);
   const bool fuse_g = (fuse || fuse_gbig) && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], B, h->skws_floats);
-  const agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
-  const agx::FusedOpt gfo{h->gp + ghole_lo, a->gen_rms + ghole_lo, gm0.dims[Lg0], a->lr_gen, a->rho, a->eps};
+  agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
+  agx::FusedOpt gfo{h->gp + ghole_lo, a->gen_rms + ghole_lo, gm0.dims[Lg0], a->lr_gen, a->rho, a->eps};
+  // ... and (one stream, no side branches) the same launch updates the rest of the flat buffer:
+  // the critic's product then takes ALL rows of W_1, and no optimizer launch is left in the step
+  const bool rest = B < side_min() && !getenv("AGX_NO_FUSED_REST");
+  const int64_t dfull_hi = dm.w_off[0] + (int64_t)dm.dims[0] * dm.ldw[0];
+  const bool rest_d = rest && dfull_hi % 4 == 0 && dfull_hi <= (dm.n_flat & ~(int64_t)3);
+  if (rest_d) {
+    dfo.rows = dm.dims[0];
+    dfo.rest_w = h->dp; dfo.rest_g = h->dg; dfo.rest_s1 = a->disc_rms;
+    dfo.rest_n = dm.n_flat; dfo.rest_hole_lo = dhole_lo; dfo.rest_hole_hi = dfull_hi;
+  }
+  if (rest) {
+    gfo.rest_w = h->gp; gfo.rest_g = h->gg; gfo.rest_s1 = a->gen_rms;
+    gfo.rest_n = gm0.n_flat; gfo.rest_hole_lo = ghole_lo; gfo.rest_hole_hi = ghole_hi;
+  }
   const bool snap = seg < 0 && !a->split && !a->disc_losses && !a->gen_losses;
   const agx::LossCopy lcopy{h->loss_slot, h->losslog, (nbc + 1) * 4};
   uint64_t sub = 0;
@@ -779,7 +807,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
                           a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dfo : nullptr));
     }
     if (in_seg(k + 1)) {
-      if (fuse_d) AGX_TRY(agx::opt_rmsprop_hole(st, h->dp, h->dg, a->disc_rms, dm.n_flat, dhole_lo, dhole_hi, a->lr_disc, a->rho, a->eps));
+      if (fuse_d && rest_d) {}   // updated by the layer-1 product's launch
+      else if (fuse_d) AGX_TRY(agx::opt_rmsprop_hole(st, h->dp, h->dg, a->disc_rms, dm.n_flat, dhole_lo, dhole_hi, a->lr_disc, a->rho, a->eps));
       else AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
     }
   }
@@ -791,7 +820,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
                      fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));
   }
   if (in_seg(nbc + 1)) {
-    if (fuse_g) AGX_TRY(agx::opt_rmsprop_hole(st, h->gp, h->gg, a->gen_rms, gm0.n_flat, ghole_lo, ghole_hi, a->lr_gen, a->rho, a->eps));
+    if (fuse_g && rest) {}     // updated by the output-layer product's launch
+    else if (fuse_g) AGX_TRY(agx::opt_rmsprop_hole(st, h->gp, h->gg, a->gen_rms, gm0.n_flat, ghole_lo, ghole_hi, a->lr_gen, a->rho, a->eps));
     else AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
   }
   return AGX_OK;

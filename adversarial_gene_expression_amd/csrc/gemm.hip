@@ -18,6 +18,7 @@
 //   row-contiguous source-> image [BK][rows]
 #include "agx_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -55,6 +56,14 @@ struct KParams {
   float *opt_w, *opt_s1;
   int opt_rows;
   float opt_lr, opt_rho, opt_eps;
+  // ... and the REST of the network's flat parameter buffer (everything outside [hole_lo, hole_hi),
+  // whose gradients earlier launches left in rest_g) is updated by workgroups appended behind the
+  // product's tiles, so a captured step needs no optimizer launch at all
+  int opt_tiles;          // workgroups [0, opt_tiles) are GEMM tiles, the others run the flat update
+  int opt_rest_blocks;
+  float *rest_w, *rest_s1;
+  const float *rest_g;
+  long long rest_n, rest_hole_lo4, rest_hole_len4;
   // SYRK only
   long long tile_begin;
   int tiles_1d;
@@ -80,6 +89,38 @@ __device__ __forceinline__ float half_wave_sum_at31(float v) {
   AGX_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
 #undef AGX_DPP_ADD
   return v;
+}
+
+// flat RMSprop over [0, rest_n) minus the hole, by workgroup `blk` of `nblk` (same expressions as
+// rmsprop_kernel in elementwise.hip: bit-identical updates)
+__device__ __forceinline__ void rest_rmsprop(const KParams &p, int blk, int nblk) {
+  const long long n4 = p.rest_n >> 2;
+  const float rho = p.opt_rho, omr = 1.f - p.opt_rho, lr = p.opt_lr, eps = p.opt_eps;
+  float4 *w4 = reinterpret_cast<float4 *>(p.rest_w);
+  const float4 *g4 = reinterpret_cast<const float4 *>(p.rest_g);
+  float4 *r4 = reinterpret_cast<float4 *>(p.rest_s1);
+  for (long long j = (long long)blk * blockDim.x + threadIdx.x; j < n4 - p.rest_hole_len4;
+       j += (long long)nblk * blockDim.x) {
+    const long long i = j < p.rest_hole_lo4 ? j : j + p.rest_hole_len4;
+    float4 wv = w4[i], gv = g4[i], rv = r4[i];
+#define AGX_RMS1(c)                                  \
+  {                                                  \
+    const float gg = gv.c * 1.f;                     \
+    rv.c = rho * rv.c + omr * (gg * gg);             \
+    wv.c = wv.c - lr * gg / (sqrtf(rv.c) + eps);     \
+  }
+    AGX_RMS1(x) AGX_RMS1(y) AGX_RMS1(z) AGX_RMS1(w)
+#undef AGX_RMS1
+    w4[i] = wv;
+    r4[i] = rv;
+  }
+  const long long i = (n4 << 2) + (long long)blk * blockDim.x + threadIdx.x;
+  if (i < p.rest_n) {
+    const float gg = p.rest_g[i] * 1.f;
+    const float r = rho * p.rest_s1[i] + omr * (gg * gg);
+    p.rest_s1[i] = r;
+    p.rest_w[i] = p.rest_w[i] - lr * gg / (sqrtf(r) + eps);
+  }
 }
 
 __device__ __forceinline__ void opt_rmsprop_apply(const KParams &p, size_t off, float g, float w, float r) {
@@ -365,16 +406,23 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
+  if (OPT && p.rest_n > 0 && (int)blockIdx.x >= p.opt_tiles) {
+    rest_rmsprop(p, (int)blockIdx.x - p.opt_tiles, (int)gridDim.x - p.opt_tiles);
+    return;
+  }
+  // tiles of the product (an OPT launch without split-K may carry extra update workgroups behind them)
+  const int gx = (OPT && p.rest_n > 0) ? p.opt_tiles : (int)gridDim.x;
+
   int tm, tn, z;
   if (SYRK) {
     tri_decode(p.tile_begin + agx::xcd_logical_id(blockIdx.x, gridDim.x), p.tiles_1d, tm, tn);
     z = 0;
   } else {
     // logical order: split-K slice major, then tile row, then tile column
-    const int lid = agx::xcd_logical_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int lid = agx::xcd_logical_id(blockIdx.x + gx * blockIdx.y, gx * gridDim.y);
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int t = lid % (int)gridDim.x;
-    z = lid / (int)gridDim.x;
+    const int t = lid % gx;
+    z = lid / gx;
     tm = t / tiles_n;
     tn = t % tiles_n;
   }
@@ -978,7 +1026,7 @@ int launch(hipStream_t st, const KParams &p, int tiles) {
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
   auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT>;  // LDS limit raised in agx_init
-  dim3 grid(tiles, p.splitk, 1), block(WM * WN * 64, 1, 1);
+  dim3 grid(tiles + ((OPT && p.rest_n > 0) ? p.opt_rest_blocks : 0), p.splitk, 1), block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
@@ -1174,6 +1222,18 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
     p.opt_w = fo->w; p.opt_s1 = fo->s1;
     p.opt_rows = fo->rows < g->M ? fo->rows : g->M;
     p.opt_lr = fo->lr; p.opt_rho = fo->rho; p.opt_eps = fo->eps;
+    if (fo->rest_n > 0) {
+      AGX_CHECK_ARG(fo->rest_w && fo->rest_g && fo->rest_s1 && fo->rest_hole_lo % 4 == 0 && fo->rest_hole_hi % 4 == 0 &&
+                        fo->rest_hole_lo >= 0 && fo->rest_hole_lo <= fo->rest_hole_hi &&
+                        fo->rest_hole_hi <= (fo->rest_n & ~(int64_t)3),
+                    "agx_gemm_f32: bad flat-update range of the fused optimizer");
+      p.rest_w = fo->rest_w; p.rest_g = fo->rest_g; p.rest_s1 = fo->rest_s1;
+      p.rest_n = fo->rest_n;
+      p.rest_hole_lo4 = fo->rest_hole_lo / 4;
+      p.rest_hole_len4 = (fo->rest_hole_hi - fo->rest_hole_lo) / 4;
+      const int64_t rest4 = (fo->rest_n >> 2) - p.rest_hole_len4;
+      p.opt_rest_blocks = (int)std::min<int64_t>(256, std::max<int64_t>(1, agx::cdiv64(rest4 + 256, 256)));
+    }
   }
   Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk, g->ws ? g->ws_floats : 0,
                       g->ta ? 2 : (g->tb ? 1 : 0));
@@ -1216,6 +1276,7 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
                       2.0 * g->M * (double)g->N * g->K,
                       4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N) +
                           (opt ? 12.0 * (double)p.opt_rows * g->N : 0.0));
+  p.opt_tiles = pl.tiles;
   int rc;
   if (opt && pl.cfg == 0)
     rc = vec ? launch<128, 128, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
