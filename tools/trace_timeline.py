@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of the LAST train iteration in a rocprofv3 --kernel-trace CSV.
+"""Timeline of one train iteration (from the middle of the run) in a rocprofv3 --kernel-trace CSV.
 
     python tools/trace_timeline.py <kernel_trace.csv> [marker-kernel-substring]
 
@@ -41,7 +41,8 @@ def main():
         print('marker not found twice; showing everything')
         lo, hi = 0, len(rows)
     else:
-        lo, hi = starts[-2], starts[-1]
+        mid = len(starts) // 2          # an iteration from the middle of the run: inside bench.py's timed (graph) region
+        lo, hi = starts[mid], starts[mid + 1]
     it = rows[lo:hi]
     busy = gaps = 0
     prev_end = it[0][0]
