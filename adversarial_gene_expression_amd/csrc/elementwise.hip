@@ -480,9 +480,48 @@ __global__ void __launch_bounds__(256) stack_rows_kernel(
 __device__ __forceinline__ void colsum_block(const float *__restrict__ A, int lda, int r0, int r1, int H,
                                              float *__restrict__ out, int blk, int weighted, int n0,
                                              int n1, float c0, float c1, float c2,
-                                             float *__restrict__ bias_out, float (*red)[64]) {
+                                             float *__restrict__ bias_out, float (*red)[64], float *svec) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int j = blk * 64 + tx;
+  if (r1 - r0 >= 128 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
+    // many rows (large batches): 16 float4 columns x 64 row phases, four 16-B loads in flight per
+    // thread - 1024 rows are 16 row steps instead of 64 (the padding columns up to lda are readable)
+    const int c4 = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    const int jc = blk * 64 + 4 * c4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (jc < H) {
+      auto wt = [&](int r) { return weighted ? (r < n0 ? c0 : (r < n0 + n1 ? c1 : c2)) : 1.f; };
+      int r = r0 + ph;
+      for (; r + 192 < r1; r += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(A + (size_t)(r + 64 * u) * lda + jc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float w = wt(r + 64 * u);
+          float4 &a = (u & 1) ? a1 : a0;
+          if (weighted) { a.x += v[u].x * w; a.y += v[u].y * w; a.z += v[u].z * w; a.w += v[u].w * w; }
+          else { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+      }
+      for (; r < r1; r += 64) {
+        const float4 v = *reinterpret_cast<const float4 *>(A + (size_t)r * lda + jc);
+        const float w = wt(r);
+        if (weighted) { a0.x += v.x * w; a0.y += v.y * w; a0.z += v.z * w; a0.w += v.w * w; }
+        else { a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w; }
+      }
+    }
+    float4 *s4 = reinterpret_cast<float4 *>(svec);   // [64 phases][16 float4 columns]
+    s4[ph * 16 + c4] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (threadIdx.x < 64 && j < H) {
+      float t = 0.f;
+      for (int k = 0; k < 64; ++k) t += svec[k * 64 + tx];
+      out[j] = t;
+    }
+    if (weighted && bias_out && blk == 0 && threadIdx.x == 0) bias_out[0] = (float)n0 * c0 + (float)n1 * c1;
+    return;
+  }
   float s = 0.f;
   if (j < H) {
     // four independent partial sums, four loads in flight (a single dependent chain of loads made
@@ -519,13 +558,13 @@ __device__ __forceinline__ void colsum_block(const float *__restrict__ A, int ld
 
 __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j, const agx::LossCopy lc) {
   __shared__ float red[16][64];
-  __shared__ float svec[4096];   // [0,2048): partial / final column sums, [2048,4096): row match flags
+  __shared__ __attribute__((aligned(16))) float svec[8192];   // [0,6144): partial / final column sums, [6144,8192): row match flags
   int blk = blockIdx.x;
   for (int c = 0; c < j.n_colsum; ++c) {
     const int nb = (j.cs_H[c] + 63) / 64;
     if (blk < nb) {
       colsum_block(j.cs_A[c], j.cs_lda[c], j.cs_r0[c], j.cs_r1[c], j.cs_H[c], j.cs_out[c], blk, 0, 0, 0,
-                   0.f, 0.f, 0.f, nullptr, red);
+                   0.f, 0.f, 0.f, nullptr, red, svec);
       return;
     }
     blk -= nb;
@@ -534,7 +573,7 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
     const int nb = (j.w_H + 63) / 64;
     if (blk < nb) {
       colsum_block(j.w_A, j.w_lda, 0, j.w_R, j.w_H, j.w_out, blk, 1, j.w_n0, j.w_n1, j.w_c0, j.w_c1,
-                   j.w_c2, j.w_bias_out, red);
+                   j.w_c2, j.w_bias_out, red, svec);
       return;
     }
     blk -= nb;
@@ -556,7 +595,68 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
       // thread groups whose partials meet in LDS in a fixed order
       // the 0/1 match of every row is staged in LDS first, so that the row loop below has no
       // dependent (index -> data) load chain: every D load is unconditional and independent
-      float *match = svec + 2048;   // rows are processed in chunks of 2048
+      float *match = svec + 6144;   // rows are processed in chunks of 2048
+      // large batches, 16-B aligned deltas: a thread owns 4 consecutive columns, the rows are dealt
+      // over 1024 / (H/4) thread groups (H = 256: 16 groups instead of 4), eight 16-B loads in flight
+      const bool vec4 = j.emb_rows >= 128 && (H & 3) == 0 && H <= 1024 && (j.emb_ldd & 3) == 0 &&
+                        (reinterpret_cast<uintptr_t>(j.emb_D) & 15) == 0;
+      if (vec4) {
+        const int cols4 = H >> 2, ng = 1024 / cols4;
+        const int kk4 = threadIdx.x % cols4, rg = threadIdx.x / cols4;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        for (int c0 = 0; c0 < j.emb_rows; c0 += 2048) {
+          const int nrow = min(2048, j.emb_rows - c0);
+          __syncthreads();
+          for (int r = threadIdx.x; r < nrow; r += 1024)
+            match[r] = j.emb_cat[(size_t)((c0 + r) % j.emb_B) * j.emb_ld_cat + i] == rowid ? 1.f : 0.f;
+          __syncthreads();
+          if (rg < ng) {
+            int r = rg;
+            for (; r + 7 * ng < nrow; r += 8 * ng) {
+              float4 d[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                d[u] = *reinterpret_cast<const float4 *>(j.emb_D + (size_t)(c0 + r + u * ng) * j.emb_ldd + 4 * kk4);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const bool mt = match[r + u * ng] != 0.f;   // select, not multiply: a NaN in another row must not leak
+                float4 &a = (u & 1) ? a1 : a0;
+                a.x += mt ? d[u].x : 0.f; a.y += mt ? d[u].y : 0.f; a.z += mt ? d[u].z : 0.f; a.w += mt ? d[u].w : 0.f;
+              }
+            }
+            for (; r < nrow; r += ng) {
+              const float4 d = *reinterpret_cast<const float4 *>(j.emb_D + (size_t)(c0 + r) * j.emb_ldd + 4 * kk4);
+              const bool mt = match[r] != 0.f;
+              a0.x += mt ? d.x : 0.f; a0.y += mt ? d.y : 0.f; a0.z += mt ? d.z : 0.f; a0.w += mt ? d.w : 0.f;
+            }
+          }
+        }
+        float4 *p4 = reinterpret_cast<float4 *>(svec);           // [ng][cols4] float4 = <= 4096 floats
+        if (rg < ng) p4[rg * cols4 + kk4] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        __syncthreads();
+        float *sfin4 = svec + 4096;                              // [H] final sums (H <= 1024)
+        if ((int)threadIdx.x < H) {
+          float t = 0.f;
+          for (int g = 0; g < ng; ++g) t += svec[(size_t)(g * cols4) * 4 + threadIdx.x];
+          sfin4[threadIdx.x] = t;
+        }
+        __syncthreads();
+        for (int d = 0; d < j.emb.edim[i]; ++d) {
+          const float *w = j.emb_W + (size_t)(coff + d) * j.emb_ldw;
+          float v = 0.f;
+          for (int k = threadIdx.x; k < H; k += 1024) v += sfin4[k] * w[k];
+          v = wave_sum(v);
+          if (lane == 0) red[0][wave] = v;
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w16 = 0; w16 < 16; ++w16) t += red[0][w16];
+            j.emb_grad[j.emb.table_off[i] + (size_t)rowid * j.emb.edim[i] + d] = t;
+          }
+          __syncthreads();
+        }
+        return;
+      }
       for (int c0 = 0; c0 < j.emb_rows || c0 == 0; c0 += 2048) {
         const int nrow = min(2048, j.emb_rows - c0);
         __syncthreads();
