@@ -101,6 +101,9 @@ class IterArgs(C.Structure):
         ('aug_mask_gen', C.c_void_p), ('aug_noise_gen', C.c_void_p),
         ('B_global', C.c_int32), ('row_lo', C.c_int32), ('split', C.c_int32),
         ('disc_losses', C.c_void_p), ('gen_losses', C.c_void_p),
+        ('opt_kind', C.c_int32), ('beta1', C.c_float), ('beta2', C.c_float),
+        ('disc_m', C.c_void_p), ('disc_v', C.c_void_p), ('gen_m', C.c_void_p), ('gen_v', C.c_void_p),
+        ('adam_lr_t_host', C.c_void_p),
     ]
 
 
@@ -195,6 +198,7 @@ SIGNATURES = {
     'agx_cgan_iter_num_segs': (_i32, [_vp]),
     'agx_cgan_iter_launch_seg': (C.c_int, [_vp, _vp, _i32]),
     'agx_cgan_iter_rng_draws': (_i64, [_vp]),
+    'agx_cgan_iter_set_lr': (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
     'agx_cgan_iter_eager': (C.c_int, [_vp, _vp, C.POINTER(IterArgs), _vp, _i32, _vp, _vp, _u64, _vp, C.POINTER(_i64)]),
     'agx_cgan_iter_destroy': (C.c_int, [_vp]),
 }

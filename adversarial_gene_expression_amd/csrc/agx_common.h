@@ -64,9 +64,17 @@ struct LossCopy {
 int small_grads_run(void *stream, const agx_small_grads_t *j, const LossCopy &lc);
 // Everything a replayed iteration needs staged, in ONE launch: B real rows into the stacked critic
 // input, covariates into their staging buffers, RNG position and loss-snapshot address.
+// (lrs: per-step Adam step sizes of the iteration about to run, copied to lr_dev[0..n))
+struct LrTable {
+  int n;
+  float v[64];
+};
 int iter_stage(void *stream, const float *x, int ldxs, float *X, int ldx, int G, int B, const int32_t *cat,
                int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
-               uint64_t rng_offset, float **loss_slot, float *losses_out);
+               uint64_t rng_offset, float **loss_slot, float *losses_out, const LrTable *lrs, float *lr_dev);
+// Adam with the bias-corrected step size read from device memory (captured iterations)
+int opt_adam_dev_lr(void *stream, float *w, const float *g, float *m, float *v, int64_t n, const float *lr_dev,
+                    float beta1, float beta2, float eps);
 // RMSprop over [0, n) minus the hole [hole_lo, hole_hi) (multiples of 4) that fused epilogues updated
 int opt_rmsprop_hole(void *stream, float *w, const float *g, float *rms, int64_t n, int64_t hole_lo,
                      int64_t hole_hi, float lr, float rho, float eps);

@@ -55,6 +55,7 @@ struct agx_cgan {
   int ldgh[AGX_MAX_LAYERS + 1] = {};
   // staging for the captured iteration (agx_cgan_iter_*)
   float *snum = nullptr, *zbuf = nullptr, *abuf = nullptr, *losslog = nullptr;
+  float *lrdev = nullptr;                   // [64] Adam step sizes of the iteration being replayed
   int32_t *scat = nullptr;
   uint64_t *rngpos = nullptr;
   float **loss_slot = nullptr;              // device word: where the last step snapshots the loss log
@@ -145,6 +146,7 @@ void carve(agx_cgan *h, float *base) {
   h->zbuf = cv.take((int64_t)S * Bm * c.z_dim);
   h->abuf = cv.take((int64_t)S * Bm);
   h->losslog = cv.take(4 * 64);
+  h->lrdev = cv.take(64);
   h->rngpos = reinterpret_cast<uint64_t *>(cv.take(16));
   h->loss_slot = h->rngpos ? reinterpret_cast<float **>(h->rngpos + 1) : nullptr;
   // split-K scratch: the largest request over the GEMM shapes of both steps
@@ -692,6 +694,8 @@ struct agx_iter_graph {
   int B = 0, nb_critic = 0;
   int64_t draws = 0;
   bool snap = false;   // the last step snapshots the loss log to the address staged per launch
+  bool adam = false;
+  agx::LrTable lrs;    // Adam: step sizes for the next replay (agx_cgan_iter_set_lr)
 };
 
 namespace {
@@ -715,10 +719,11 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const int Lg0 = gm0.n_layers - 1;
   const int64_t dhole_lo = dm.w_off[0], dhole_hi = dm.w_off[0] + (int64_t)G * dm.ldw[0];
   const int64_t ghole_lo = gm0.w_off[Lg0], ghole_hi = gm0.w_off[Lg0] + (int64_t)gm0.dims[Lg0] * gm0.ldw[Lg0];
-  const bool fuse = seg < 0 && !a->split && B < 128 && !getenv("AGX_NO_FUSED_OPT");
+  const bool adam = a->opt_kind == 1;
+  const bool fuse = seg < 0 && !a->split && B < 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
   // from 128 rows on the critic's product always fuses (+0.7 % at 512 rows); the generator's only while
   // its weight gradients are not on a side stream (AGX_SIDE_MIN), or AGX_FUSE_GEN_BIG=0
-  const bool fuse_big = seg < 0 && !a->split && B >= 128 && !getenv("AGX_NO_FUSED_OPT");
+  const bool fuse_big = seg < 0 && !a->split && B >= 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
   static const bool gen_big = !(getenv("AGX_FUSE_GEN_BIG") && atoi(getenv("AGX_FUSE_GEN_BIG")) == 0);
   const bool fuse_gbig = fuse_big && gen_big && B < side_min();
   const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
@@ -809,7 +814,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
                           a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dfo : nullptr));
     }
     if (in_seg(k + 1)) {
-      if (fuse_d && rest_d) {}   // updated by the layer-1 product's launch
+      if (adam) AGX_TRY(agx::opt_adam_dev_lr(st, h->dp, h->dg, a->disc_m, a->disc_v, dm.n_flat, h->lrdev + k, a->beta1, a->beta2, a->eps));
+      else if (fuse_d && rest_d) {}   // updated by the layer-1 product's launch
       else if (fuse_d) AGX_TRY(agx::opt_rmsprop_hole(st, h->dp, h->dg, a->disc_rms, dm.n_flat, dhole_lo, dhole_hi, a->lr_disc, a->rho, a->eps));
       else AGX_TRY(agx_opt_rmsprop(st, h->dp, h->dg, a->disc_rms, h->cfg.disc.n_flat, a->lr_disc, a->rho, a->eps, 1.f));
     }
@@ -822,7 +828,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
                      fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));
   }
   if (in_seg(nbc + 1)) {
-    if (fuse_g && rest) {}     // updated by the output-layer product's launch
+    if (adam) AGX_TRY(agx::opt_adam_dev_lr(st, h->gp, h->gg, a->gen_m, a->gen_v, gm0.n_flat, h->lrdev + nbc, a->beta1, a->beta2, a->eps));
+    else if (fuse_g && rest) {}     // updated by the output-layer product's launch
     else if (fuse_g) AGX_TRY(agx::opt_rmsprop_hole(st, h->gp, h->gg, a->gen_rms, gm0.n_flat, ghole_lo, ghole_hi, a->lr_gen, a->rho, a->eps));
     else AGX_TRY(agx_opt_rmsprop(st, h->gp, h->gg, a->gen_rms, h->cfg.gen.n_flat, a->lr_gen, a->rho, a->eps, 1.f));
   }
@@ -840,7 +847,9 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   AGX_CHECK_ARG(a->B_global == 0 || (a->B_global >= a->B && a->row_lo >= 0 && a->row_lo + a->B <= a->B_global),
                 "agx_cgan_iter_capture: rows [%d, %d) outside the global batch %d", a->row_lo, a->row_lo + a->B, a->B_global);
   AGX_CHECK_ARG(a->B_global != 0 || a->row_lo == 0, "agx_cgan_iter_capture: row_lo without B_global");
-  AGX_CHECK_ARG(a->disc_rms && a->gen_rms, "agx_cgan_iter_capture: optimizer slots missing");
+  AGX_CHECK_ARG(a->opt_kind == 0 || a->opt_kind == 1, "agx_cgan_iter_capture: opt_kind %d", a->opt_kind);
+  AGX_CHECK_ARG(a->opt_kind == 1 ? (a->disc_m && a->disc_v && a->gen_m && a->gen_v) : (a->disc_rms && a->gen_rms),
+                "agx_cgan_iter_capture: optimizer slots missing");
   AGX_CHECK_ARG(!a->aug_mask_disc || (a->aug_noise_fake && a->aug_noise_real), "agx_cgan_iter_capture: critic aug noise missing");
   AGX_CHECK_ARG(!a->aug_mask_gen || a->aug_noise_gen, "agx_cgan_iter_capture: generator aug noise missing");
   AGX_CHECK_ARG(stream != nullptr, "agx_cgan_iter_capture: capture needs a non-default stream");
@@ -853,6 +862,8 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   AGX_CHECK_ARG(g, "agx_cgan_iter_capture: out of host memory");
   g->h = h; g->B = a->B; g->nb_critic = a->nb_critic;
   g->snap = !a->split && !a->disc_losses && !a->gen_losses;
+  g->adam = a->opt_kind == 1;
+  g->lrs.n = 0;
   const int nseg = a->split ? a->nb_critic + 2 : 1;
   for (int s = 0; s < nseg; ++s) {
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
@@ -893,8 +904,12 @@ extern "C" int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const floa
   const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
   AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_stage: covariates missing");
   // one launch: real rows straight into rows [0,B) of stacked-input buffer 0, covariates, RNG position
+  if (g->adam && g->lrs.n != g->nb_critic + 1) {
+    agx::set_error("agx_cgan_iter_stage: Adam iteration needs agx_cgan_iter_set_lr(%d values) first", g->nb_critic + 1);
+    return AGX_E_STATE;
+  }
   return agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum, B * nnum,
-                         h->rngpos, rng_offset, h->loss_slot, nullptr);
+                         h->rngpos, rng_offset, h->loss_slot, nullptr, g->adam ? &g->lrs : nullptr, h->lrdev);
 }
 
 extern "C" int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g) { return g ? g->nseg : 0; }
@@ -916,8 +931,13 @@ extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const flo
     const int B = g->B, ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
     AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_launch: covariates missing");
     // the graph's last small-gradient launch copies the loss log to losses_out (address staged here)
+    if (g->adam && g->lrs.n != g->nb_critic + 1) {
+      agx::set_error("agx_cgan_iter_launch: Adam iteration needs agx_cgan_iter_set_lr(%d values) first", g->nb_critic + 1);
+      return AGX_E_STATE;
+    }
     AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum,
-                            B * nnum, h->rngpos, rng_offset, h->loss_slot, losses_out));
+                            B * nnum, h->rngpos, rng_offset, h->loss_slot, losses_out, g->adam ? &g->lrs : nullptr,
+                            h->lrdev));
     for (int s = 0; s < g->nseg; ++s) AGX_HIP(hipGraphLaunch(g->exec[s], st));
     return AGX_OK;
   }
@@ -931,6 +951,13 @@ extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const flo
 
 extern "C" int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g) { return g ? g->draws : 0; }
 
+extern "C" int agx_cgan_iter_set_lr(agx_iter_graph_t *g, const float *lr_t_host, int32_t n) {
+  AGX_CHECK_ARG(g && lr_t_host && n == g->nb_critic + 1 && n <= 64, "agx_cgan_iter_set_lr: need nb_critic + 1 values");
+  g->lrs.n = n;
+  for (int i = 0; i < n; ++i) g->lrs.v[i] = lr_t_host[i];
+  return AGX_OK;
+}
+
 extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_args_t *a, const float *x,
                                    int32_t ldx, const int32_t *cat, const float *num, uint64_t rng_offset,
                                    float *losses_out, int64_t *draws_out) {
@@ -938,13 +965,23 @@ extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_a
   if (!h->bound) { agx::set_error("agx_cgan_iter_eager: not bound"); return AGX_E_STATE; }
   AGX_CHECK_ARG(a->B > 0 && a->B <= h->Bm && ldx >= h->G, "agx_cgan_iter_eager: batch %d outside (0, %d] or ldx < x_dim", a->B, h->Bm);
   AGX_CHECK_ARG(a->nb_critic >= 0 && a->nb_critic < h->S, "agx_cgan_iter_eager: nb_critic %d needs max_steps > %d", a->nb_critic, a->nb_critic);
-  AGX_CHECK_ARG(!a->split && a->disc_rms && a->gen_rms, "agx_cgan_iter_eager: one-GPU form only; optimizer slots required");
+  AGX_CHECK_ARG(!a->split, "agx_cgan_iter_eager: one-GPU form only");
+  AGX_CHECK_ARG(a->opt_kind == 1 ? (a->disc_m && a->disc_v && a->gen_m && a->gen_v && a->adam_lr_t_host)
+                                 : (a->opt_kind == 0 && a->disc_rms && a->gen_rms),
+                "agx_cgan_iter_eager: optimizer slots (and adam_lr_t_host for Adam) required");
+  agx::LrTable lrs;
+  lrs.n = 0;
+  if (a->opt_kind == 1) {
+    lrs.n = a->nb_critic + 1;
+    for (int i = 0; i < lrs.n; ++i) lrs.v[i] = a->adam_lr_t_host[i];
+  }
   const int ncat = h->cfg.gen.emb.n_cat, nnum = h->cfg.gen.n_num;
   AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_eager: covariates missing");
   hipStream_t st = agx::as_stream(stream);
   const bool snap = !a->disc_losses && !a->gen_losses;
   AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, a->B, cat, h->scat, a->B * ncat, num, h->snum,
-                          a->B * nnum, h->rngpos, rng_offset, h->loss_slot, snap ? losses_out : nullptr));
+                          a->B * nnum, h->rngpos, rng_offset, h->loss_slot, snap ? losses_out : nullptr,
+                          lrs.n ? &lrs : nullptr, h->lrdev));
   int64_t draws = 0;
   AGX_TRY(record_iteration(h, st, a, -1, &draws));
   if (draws_out) *draws_out = draws;

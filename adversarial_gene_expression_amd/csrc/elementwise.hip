@@ -319,7 +319,10 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ w,
                                                    const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v,
                                                    long long n, float lr_t, float b1, float b2,
-                                                   float eps, float gs) {
+                                                   float eps, float gs, const float *__restrict__ lr_dev) {
+  // lr_dev: bias-corrected step size staged in device memory (a replayed graph cannot carry a
+  // per-step scalar argument); the host computes it exactly as for the eager call
+  if (lr_dev) lr_t = *lr_dev;
   const float omb1 = 1.f - b1, omb2 = 1.f - b2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -764,7 +767,8 @@ __global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict
                                                          const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
                                                          const float *__restrict__ num, float *__restrict__ snum, int n_num,
                                                          unsigned long long *rngpos, unsigned long long rng_offset,
-                                                         float **loss_slot, float *losses_out) {
+                                                         float **loss_slot, float *losses_out,
+                                                         const agx::LrTable lrs, float *__restrict__ lr_dev) {
   const int b = blockIdx.y;
   const float *s = x + (size_t)b * ldxs;
   float *d = X + (size_t)b * ldx;
@@ -784,6 +788,7 @@ __global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict
       *rngpos = rng_offset;
       *loss_slot = losses_out;
     }
+    if ((int)threadIdx.x < lrs.n) lr_dev[threadIdx.x] = lrs.v[threadIdx.x];
   }
 }
 
@@ -979,7 +984,18 @@ extern "C" int agx_opt_adam(void *stream, float *w, const float *g, float *m, fl
   agx::ProfScope prof(agx::as_stream(stream), AGX_K_OPT_ADAM, 10.0 * n, 28.0 * n);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0,
                      agx::as_stream(stream), w, g, m, v, (long long)n, lr_t, beta1, beta2, eps,
-                     grad_scale);
+                     grad_scale, (const float *)nullptr);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int agx::opt_adam_dev_lr(void *stream, float *w, const float *g, float *m, float *v, int64_t n, const float *lr_dev,
+                         float beta1, float beta2, float eps) {
+  AGX_CHECK_ARG(w && g && m && v && lr_dev && n >= 0, "opt_adam_dev_lr: bad argument");
+  if (n == 0) return AGX_OK;
+  agx::ProfScope prof(agx::as_stream(stream), AGX_K_OPT_ADAM, 10.0 * n, 28.0 * n);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, agx::as_stream(stream), w, g, m, v,
+                     (long long)n, 0.f, beta1, beta2, eps, 1.f, lr_dev);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
@@ -1114,12 +1130,14 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
 
 int agx::iter_stage(void *stream, const float *x, int ldxs, float *X, int ldx, int G, int B, const int32_t *cat,
                     int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
-                    uint64_t rng_offset, float **loss_slot, float *losses_out) {
+                    uint64_t rng_offset, float **loss_slot, float *losses_out, const agx::LrTable *lrs, float *lr_dev) {
+  agx::LrTable none;
+  none.n = 0;
   const int vec = agx::aligned16(x) && agx::aligned16(X) && ldxs % 4 == 0 && ldx % 4 == 0;
   const int gx = std::max(1, std::min(8, agx::cdiv(G, 4 * 256)));
   hipLaunchKernelGGL(iter_stage_kernel, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, ldx, G, vec,
                      cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
-                     (unsigned long long)rng_offset, loss_slot, losses_out);
+                     (unsigned long long)rng_offset, loss_slot, losses_out, (lrs && lr_dev) ? *lrs : none, lr_dev);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

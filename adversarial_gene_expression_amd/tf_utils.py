@@ -433,14 +433,20 @@ class Adam:
         self._state = {}
         self.iterations = 0
 
-    def apply(self, net, grad_scale=1.0):
-        lib = _lib.load()
+    def slot(self, net):
         st = self._state.get(id(net))
         if st is None:
             st = self._state[id(net)] = [_dev.zeros(net.n_flat), _dev.zeros(net.n_flat), 0]
+        return st
+
+    def lr_t(self, t):
+        return self.learning_rate * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+    def apply(self, net, grad_scale=1.0):
+        lib = _lib.load()
+        st = self.slot(net)
         st[2] += 1
-        t = st[2]
-        lr_t = self.learning_rate * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        lr_t = self.lr_t(st[2])
         _lib.check(lib.agx_opt_adam(_dev.stream(), ptr(net.params), ptr(net.grads), ptr(st[0]), ptr(st[1]), net.n_flat,
                                     lr_t, self.beta_1, self.beta_2, self.epsilon, grad_scale), 'agx_opt_adam')
         self.iterations += 1
@@ -488,8 +494,14 @@ class _Pair:
         a = _lib.IterArgs()
         a.B, a.nb_critic, a.gp_weight = B, nb_critic, gp_weight
         a.lr_disc, a.lr_gen = disc_opt.learning_rate, gen_opt.learning_rate
-        a.rho, a.eps = disc_opt.rho, disc_opt.epsilon
-        a.disc_rms, a.gen_rms = ptr(disc_opt.slot(disc)), ptr(gen_opt.slot(gen))
+        a.eps = disc_opt.epsilon
+        if type(disc_opt) is Adam:
+            a.opt_kind, a.beta1, a.beta2 = 1, disc_opt.beta_1, disc_opt.beta_2
+            sd, sg = disc_opt.slot(disc), gen_opt.slot(gen)
+            a.disc_m, a.disc_v, a.gen_m, a.gen_v = ptr(sd[0]), ptr(sd[1]), ptr(sg[0]), ptr(sg[1])
+        else:
+            a.rho = disc_opt.rho
+            a.disc_rms, a.gen_rms = ptr(disc_opt.slot(disc)), ptr(gen_opt.slot(gen))
         a.seed = int(seed)
         if aug_d is not None:
             a.aug_mask_disc, a.aug_noise_fake, a.aug_noise_real = (ptr(aug_d['mask']), ptr(aug_d['noise_fake']),
@@ -511,6 +523,9 @@ class _Pair:
         lib = _lib.load()
         B = x.shape[0]
         a = self._iter_args(gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, None, None, B, 0, False)
+        if type(disc_opt) is Adam:
+            lrs = _adam_step_sizes(gen, disc, gen_opt, disc_opt, nb_critic)
+            a.adam_lr_t_host = _lib.C.cast(lrs, _lib.C.c_void_p)
         draws = _lib.C.c_int64(0)
         _lib.check(lib.agx_cgan_iter_eager(self.handle, _dev.stream(), a, ptr(x), x.stride(0), ptr(cc), ptr(nc),
                                            int(rng_offset), ptr(losses) if losses is not None else None,
@@ -680,8 +695,25 @@ def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None,
 
 
 def _graph_ok(gen_opt, disc_opt, world=1):
-    return (type(gen_opt) is RMSprop and type(disc_opt) is RMSprop
-            and gen_opt.rho == disc_opt.rho and gen_opt.epsilon == disc_opt.epsilon)
+    if type(gen_opt) is RMSprop and type(disc_opt) is RMSprop:
+        return gen_opt.rho == disc_opt.rho and gen_opt.epsilon == disc_opt.epsilon
+    if type(gen_opt) is Adam and type(disc_opt) is Adam:
+        return (gen_opt.beta_1 == disc_opt.beta_1 and gen_opt.beta_2 == disc_opt.beta_2
+                and gen_opt.epsilon == disc_opt.epsilon)
+    return False
+
+
+def _adam_step_sizes(gen, disc, gen_opt, disc_opt, nb_critic):
+    """Bias-corrected step sizes of the coming iteration (nb_critic critic steps, then the generator
+    step), computed on the host exactly as Adam.apply does; advances both step counters."""
+    sd, sg = disc_opt.slot(disc), gen_opt.slot(gen)
+    lrs = (_lib.C.c_float * (nb_critic + 1))()
+    for k in range(nb_critic):
+        lrs[k] = disc_opt.lr_t(sd[2] + 1 + k)
+    lrs[nb_critic] = gen_opt.lr_t(sg[2] + 1)
+    sd[2] += nb_critic
+    sg[2] += 1
+    return lrs
 
 
 def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_penalty_weight=10, p_aug=0,
@@ -696,7 +728,7 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
     ``[row_lo, row_lo + len(x))`` of a global batch of ``batch_global`` rows: the iteration is
     captured as nb_critic+2 graph segments with one RCCL sum all-reduce of the flat gradient buffer
     between them; draws are the global batch's, so R ranks reproduce the one-GPU big-batch run.
-    RMSprop on both nets (the reference defaults); ``train`` falls back to the eager step
+    RMSprop (the reference default) or Adam on both nets; ``train`` falls back to the eager step
     functions otherwise."""
     lib = _lib.load()
     x = _dev.to_dev(x)
@@ -705,7 +737,8 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
     B = x.shape[0]
     world, _ = _world()
     if not _graph_ok(gen_opt, disc_opt):
-        raise ValueError('train_iteration needs RMSprop on both networks')
+        raise ValueError('train_iteration needs the same optimizer class (RMSprop or Adam) with equal decay rates / '
+                         'epsilon on both networks')
     Bg = int(batch_global) if batch_global else B * world
     if world == 1 and Bg != B:
         raise ValueError('batch_global differs from the local batch on a single GPU')
@@ -717,6 +750,9 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
         aug_g = _aug_constants('gen', (id(gen), id(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
     g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, grad_penalty_weight, _rng.seed, aug_d, aug_g,
                              batch_global=Bg, row_lo=row_lo, split=world > 1)
+    if type(disc_opt) is Adam:
+        lrs = _adam_step_sizes(gen, disc, gen_opt, disc_opt, nb_critic)
+        _lib.check(lib.agx_cgan_iter_set_lr(g, lrs, nb_critic + 1), 'agx_cgan_iter_set_lr')
     if world == 1:
         losses = _dev.empty((nb_critic + 1, 4))
         _lib.check(lib.agx_cgan_iter_launch(g, _dev.stream(), ptr(x), x.stride(0), ptr(cc), ptr(nc), _rng.offset,

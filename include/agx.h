@@ -359,6 +359,15 @@ typedef struct agx_iter_args {
   /* gradient all-reduce.                                                                           */
   int32_t B_global, row_lo, split;
   float *disc_losses, *gen_losses;
+  /* optimizer of the captured iteration: 0 = RMSprop (fields above), 1 = Keras-v2 Adam on both nets   */
+  /* (tf_utils.py:261-262 takes optimizer objects).  Adam: slots m / v per net, eps above; the          */
+  /* bias-corrected step sizes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) change every step, so the HOST supplies  */
+  /* the nb_critic + 1 values of the coming iteration (critic steps, then the generator step):          */
+  /* agx_cgan_iter_set_lr before a replay, adam_lr_t_host for agx_cgan_iter_eager.                      */
+  int32_t opt_kind;
+  float beta1, beta2;
+  float *disc_m, *disc_v, *gen_m, *gen_v;
+  const float *adam_lr_t_host;
 } agx_iter_args_t;
 #define AGX_MAX_ITER_SEGS 66
 typedef struct agx_iter_graph agx_iter_graph_t;
@@ -378,6 +387,8 @@ int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const float *x, int32
 int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g);
 int agx_cgan_iter_launch_seg(agx_iter_graph_t *g, void *stream, int32_t seg);
 int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g);
+/* Adam only: the n = nb_critic + 1 step sizes the next agx_cgan_iter_launch / _stage will put in device memory. */
+int agx_cgan_iter_set_lr(agx_iter_graph_t *g, const float *lr_t_host, int32_t n);
 /* The same launch sequence as the captured one-GPU iteration (fused epilogues included), queued
  * directly on `stream` instead of replayed: what agx_prof_* brackets (events cannot be captured) and
  * debuggers see.  With profiling enabled the side-stream branches run in line.  *draws_out (host,

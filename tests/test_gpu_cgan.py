@@ -232,6 +232,31 @@ def test_ragged_and_max_batch_growth(gpu):
         _check_grads(disc.get_gradients(), [g.numpy() for g in want])
 
 
+def test_adam_graph_iteration_is_bit_identical_to_eager(gpu):
+    """Adam on both networks (``train(..., gen_opt=Adam, disc_opt=Adam)``, tf_utils.py:261-262): the captured
+    iteration reads each step's bias-corrected step size from device memory (staged per replay by the host,
+    computed as for the eager call), so graph and eager runs agree bit for bit - weights, both moment slots,
+    step counters, losses."""
+    from adversarial_gene_expression_amd import tf_utils as T
+    p = make_problem(G=61, B=70, H=(24, 16), seed=63)
+    x32 = p['x'].astype(np.float32)
+    out = []
+    for use_graph in (False, True):
+        _, gen, disc = _models(p)
+        T.set_seed(4321)
+        go, do = T.Adam(2e-4, beta_1=0.5), T.Adam(2e-4, beta_1=0.5)
+        tr = T.train(x32, p['cc'], _f32(p, 'nc'), p['Z'], 3, 32, gen, disc, lambda g: 0.0, lambda: None, gen_opt=go,
+                     disc_opt=do, verbose=False, use_graph=use_graph)
+        sd, sg = do.state_arrays(disc), go.state_arrays(gen)
+        out.append((gen.get_weights() + disc.get_weights() + sd['m'] + sd['v'] + sg['m'] + sg['v'], tr,
+                    do.slot(disc)[2], go.slot(gen)[2], T._rng.offset))
+    (w0, tr0, td0, tg0, o0), (w1, tr1, td1, tg1, o1) = out
+    assert (td0, tg0, o0) == (td1, tg1, o1) and td0 == 3 * 3 * 5 and tg0 == 3 * 3
+    for a, b in zip(w0, w1):
+        np.testing.assert_array_equal(a, b)
+    assert tr0['gen_loss'] == tr1['gen_loss'] and tr0['disc_loss'] == tr1['disc_loss']
+
+
 @pytest.mark.parametrize('p_aug', [0, 0.25])
 def test_graph_iteration_is_bit_identical_to_eager(gpu, p_aug):
     """train(use_graph=True) replays one hipGraph per iteration; with equal Philox seeds it must give
