@@ -150,6 +150,7 @@ SIGNATURES = {
     'agx_prof_spin': (C.c_int, [_vp, _i32]),
     'agx_prof_enabled': (C.c_int, []),
     'agx_prof_clock': (C.c_int, [_vp, _i32, _i32, _vp]),
+    'agx_sizeof': (_i64, [_i32]),
     'agx_gemm_f32': (C.c_int, [_vp, C.POINTER(GemmDesc)]),
     'agx_gemm_ws_floats': (_i64, [_i32, _i32, _i32]),
     'agx_embed_concat_fwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32,

@@ -1125,6 +1125,8 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
       // (one workgroup per CU measured best at the 18k-gene shapes: 64 x 256 x 18161 takes 13.8 us
       // with 16 slices vs 15.8 with 32; 32 x 256 x 18154 10.6 us with 32 slices vs 12.1 with 64)
       if (K > 512) {
+        // (with the tail kernels reducing the slabs, 2 or 3 workgroups per CU still lose: the product
+        // gains 4-7 us per iteration, the tails lose 10-35)
         sk = std::min(agx::cdiv(K, 128), agx::cdiv(cus, pl.tiles));
         if (sk > agx::cdiv(K, 128)) sk = agx::cdiv(K, 128);
       }

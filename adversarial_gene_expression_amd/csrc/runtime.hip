@@ -38,3 +38,17 @@ extern "C" int agx_init(int device) {
   AGX_TRY(agx::gemm_prepare_device());
   return AGX_OK;
 }
+
+extern "C" int64_t agx_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return sizeof(agx_gemm_t);
+    case 1: return sizeof(agx_embed_t);
+    case 2: return sizeof(agx_small_grads_t);
+    case 3: return sizeof(agx_rng_seg_t);
+    case 4: return sizeof(agx_mlp_desc_t);
+    case 5: return sizeof(agx_cgan_config_t);
+    case 6: return sizeof(agx_step_args_t);
+    case 7: return sizeof(agx_iter_args_t);
+    default: return -1;
+  }
+}

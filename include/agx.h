@@ -41,6 +41,10 @@ int agx_version(void);
 const char *agx_last_error(void);
 /* Select `device`, verify it is a gfx950 part, cache its CU count. */
 int agx_init(int device);
+/* sizeof() of the by-pointer structs below as this library was compiled (binding self-check):
+ * 0 agx_gemm_t, 1 agx_embed_t, 2 agx_small_grads_t, 3 agx_rng_seg_t, 4 agx_mlp_desc_t,
+ * 5 agx_cgan_config_t, 6 agx_step_args_t, 7 agx_iter_args_t; -1 for any other index. */
+int64_t agx_sizeof(int32_t which);
 
 /* ---- in-stream kernel timing (measurement only; no reference counterpart) ----
  * When enabled, every launch site tagged with a kernel-class id brackets its launch(es)

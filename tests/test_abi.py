@@ -31,6 +31,13 @@ def test_struct_sizes_match_header_layout():
     from adversarial_gene_expression_amd import _lib
     assert ctypes.sizeof(_lib.EmbedDesc) == 8 + 64 + 64 + 128 - 4 + 4  # int32 + pad, 2 x int32[16], int64[16]
     assert ctypes.sizeof(_lib.GemmDesc) % 8 == 0 and ctypes.sizeof(_lib.StepArgs) % 8 == 0
+    # every mirror against the size the library itself was compiled with
+    lib = _lib.load()
+    mirrors = [_lib.GemmDesc, _lib.EmbedDesc, _lib.SmallGrads, _lib.RngSeg, _lib.MlpDesc, _lib.CganConfig,
+               _lib.StepArgs, _lib.IterArgs]
+    for i, m in enumerate(mirrors):
+        assert lib.agx_sizeof(i) == ctypes.sizeof(m), (m.__name__, lib.agx_sizeof(i), ctypes.sizeof(m))
+    assert lib.agx_sizeof(len(mirrors)) == -1
 
 
 def test_host_side_validation_and_queries_without_gpu():
