@@ -1356,6 +1356,7 @@ extern "C" int agx_corr_xtx(void *stream, const float *xs, int32_t ldx, int32_t 
   const double share = (double)tiles / (double)total;
   agx::ProfScope prof(st, AGX_K_CORR_XTX, share * (double)N * G * ((double)G + 1.0),
                       4.0 * share * ((double)N * G + (double)G * G));
+  // (an 8-wave 2x4 workgroup and a BK = 64 variant measured 118.9 and 110.2 TFLOP/s against 119.9 at 18154 x 100000)
   return vec ? launch<128, 128, 2, 2, true, false, true, true>(st, p, tiles)
              : launch<128, 128, 2, 2, true, false, false, true>(st, p, tiles);
 }
