@@ -61,7 +61,22 @@ struct LossCopy {
   const float *src;
   int n;
 };
-int small_grads_run(void *stream, const agx_small_grads_t *j, const LossCopy &lc);
+// Tiny TN weight-gradient products C[M,N] = A[K,M]^T . B[K,N] carried by the small-gradient launch
+// (one wave per 32x32 output tile over the whole K, fragments straight from global memory): at batch
+// 32 a hidden-layer gradient is a 5 us launch around 2 us of work.
+struct TnJobs {
+  int n;
+  struct Job {
+    const float *A, *B;
+    float *C;
+    int lda, ldb, ldc, M, N, K;
+  } job[AGX_MAX_LAYERS];
+};
+// true if a product of this shape may ride the small-gradient launch (few tiles, short K)
+static inline bool tn_job_ok(int M, int N, int K) {
+  return K <= 256 && (int64_t)((M + 31) / 32) * ((N + 31) / 32) <= 256;
+}
+int small_grads_run(void *stream, const agx_small_grads_t *j, const LossCopy &lc, const TnJobs *tn = nullptr);
 // Everything a replayed iteration needs staged, in ONE launch: B real rows into the stacked critic
 // input, covariates into their staging buffers, RNG position and loss-snapshot address.
 // (lrs: per-step Adam step sizes of the iteration about to run, copied to lr_dev[0..n))

@@ -224,6 +224,11 @@ int side_min() {
   static const int v = getenv("AGX_SIDE_MIN") ? atoi(getenv("AGX_SIDE_MIN")) : 1 << 30;
   return v;
 }
+// tiny hidden-layer weight gradients inside the small-gradient launch (AGX_NO_TN_FUSE: own GEMM launches)
+bool tn_fuse() {
+  static const bool v = getenv("AGX_NO_TN_FUSE") == nullptr;
+  return v;
+}
 int dbl_min() {
   static const int v = getenv("AGX_DBL_MIN") ? atoi(getenv("AGX_DBL_MIN")) : 1 << 30;
   return v;
@@ -433,9 +438,17 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   // it overwrites the covariate rows of W_1 the embedding gradient reads and needs every other
   // gradient of the step complete.
   const bool dw1_last = fo && fo->rest_n > 0;
+  // hidden-layer products of a few 32x32 tiles over K = 3B rows ride the small-gradient launch
+  agx::TnJobs tn;
+  tn.n = 0;
   auto weight_grad = [&](int l) -> int {
     const float *in = l == 0 ? h->X : h->A[l];
     const int ldin = l == 0 ? ldx : h->ldh[l];
+    if (l > 0 && !side && tn_fuse() && agx::tn_job_ok(m.dims[l], m.dims[l + 1], R)) {
+      tn.job[tn.n++] = agx::TnJobs::Job{in, h->D[l + 1], h->dg + m.w_off[l], ldin, h->ldh[l + 1], m.ldw[l],
+                                        m.dims[l], m.dims[l + 1], R};
+      return AGX_OK;
+    }
     Gemm g(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l], m.dims[l],
            m.dims[l + 1], R);
     g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID);
@@ -467,7 +480,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   }
   j.l_losses = losses; j.l_out = h->out; j.l_slopes = h->slopes; j.l_n0 = B; j.l_n1 = B; j.l_ns = B;
   j.l_inv_b = invb; j.l_gp_weight = gp_weight; j.l_fake_sign = 1.f;
-  AGX_TRY(agx_small_grads(s_small, &j));
+  AGX_TRY(agx::small_grads_run(s_small, &j, agx::LossCopy{nullptr, nullptr, 0}, &tn));
   if (dw1_last) AGX_TRY(weight_grad(0));
   if (side) {
     AGX_TRY(join_from(h, st, 0));
@@ -494,6 +507,8 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   const bool side = B >= side_min() && !agx_prof_enabled();
   agx_small_grads_t j;
   memset(&j, 0, sizeof(j));
+  agx::TnJobs tn;
+  tn.n = 0;
   const float *dout = dX;
   int lddout = ldx;
   for (int l = Lg; l >= 0; --l) {
@@ -509,7 +524,11 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
       if (fused) g.opt(fo);
       return g.run(s);
     };
-    if (!fused) {
+    if (!fused && !side && tn_fuse() && agx::tn_job_ok(gm.dims[l], gm.dims[l + 1], B)) {
+      // a few 32x32 tiles over K = B rows: rides the small-gradient launch at the end of the step
+      tn.job[tn.n++] = agx::TnJobs::Job{in, dout, h->gg + gm.w_off[l], ldin, lddout, gm.ldw[l], gm.dims[l],
+                                        gm.dims[l + 1], B};
+    } else if (!fused) {
       if (side) AGX_TRY(fork_to(h, st, 0));
       AGX_TRY(weight_grad(side ? h->aux[0] : st, side));
     }
@@ -535,7 +554,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   }
   j.l_losses = losses; j.l_out = h->out; j.l_n0 = B; j.l_n1 = 0; j.l_ns = 0;   // mean(-D(fake))  :253
   j.l_inv_b = invb; j.l_gp_weight = 0.f; j.l_fake_sign = 1.f;
-  AGX_TRY(agx::small_grads_run(st, &j, lc ? *lc : agx::LossCopy{nullptr, nullptr, 0}));
+  AGX_TRY(agx::small_grads_run(st, &j, lc ? *lc : agx::LossCopy{nullptr, nullptr, 0}, &tn));
   if (side) AGX_TRY(join_from(h, st, 0));
   if (fo && fo->rest_n > 0) {
     // output-layer product LAST: its launch also runs the flat update of every other generator

@@ -559,10 +559,65 @@ __device__ __forceinline__ void colsum_block(const float *__restrict__ A, int ld
   if (weighted && bias_out && blk == 0 && threadIdx.x == 0) bias_out[0] = (float)n0 * c0 + (float)n1 * c1;
 }
 
-__global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j, const agx::LossCopy lc) {
+// One wave = one 32x32 tile of C = A^T . B over the whole K (v_mfma_f32_32x32x2_f32, k ascending in
+// one accumulator: a fixed summation order).  Lane (i = lane & 31, h = lane >> 5) feeds k = 8g + 4h + e of
+// row / column i, the same k for both operands; loads are clamped into the operands and masked after.
+typedef float tn_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile) {
+  const int tiles_n = (t.N + 31) / 32;
+  if (tile >= ((t.M + 31) / 32) * tiles_n) return;
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+  const bool mv = m0 + i < t.M, nv = n0 + i < t.N;
+  const float *__restrict__ a = t.A + min(m0 + i, t.M - 1);
+  const float *__restrict__ b = t.B + min(n0 + i, t.N - 1);
+  tn_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int U = 6;
+  const int ngroups = (t.K + 7) / 8, kl = t.K - 1;
+  for (int g0 = 0; g0 < ngroups; g0 += U) {
+    float av[U][4], bv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kc = min(8 * (g0 + u) + 4 * h + e, kl);
+        av[u][e] = a[(size_t)kc * t.lda];
+        bv[u][e] = b[(size_t)kc * t.ldb];
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool kv = 8 * (g0 + u) + 4 * h + e <= kl;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((kv && mv) ? av[u][e] : 0.f, (kv && nv) ? bv[u][e] : 0.f, acc, 0, 0, 0);
+      }
+  }
+  if (nv) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < t.M) t.C[(size_t)row * t.ldc + n0 + i] = acc[r];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j, const agx::LossCopy lc,
+                                                           const agx::TnJobs tn) {
   __shared__ float red[16][64];
   __shared__ __attribute__((aligned(16))) float svec[8192];   // [0,6144): partial / final column sums, [6144,8192): row match flags
   int blk = blockIdx.x;
+  // blocks in front: the tiny weight-gradient products, 4 tiles per block - one wave per SIMD (16 tiles
+  // on one CU queue 4 waves' MFMAs per SIMD: the launch grew from 8.5 to 13 us); waves 4..15 leave
+  for (int q = 0; q < tn.n; ++q) {
+    const int nb = (((tn.job[q].M + 31) / 32) * ((tn.job[q].N + 31) / 32) + 3) / 4;
+    if (blk < nb) {
+      if (threadIdx.x < 256) tn_wave_tile(tn.job[q], blk * 4 + (int)(threadIdx.x >> 6));
+      return;
+    }
+    blk -= nb;
+  }
   for (int c = 0; c < j.n_colsum; ++c) {
     const int nb = (j.cs_H[c] + 63) / 64;
     if (blk < nb) {
@@ -1097,9 +1152,21 @@ extern "C" int agx_small_grads(void *stream, const agx_small_grads_t *j) {
   return agx::small_grads_run(stream, j, agx::LossCopy{nullptr, nullptr, 0});
 }
 
-int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::LossCopy &lc) {
+int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::LossCopy &lc, const agx::TnJobs *tn) {
   AGX_CHECK_ARG(j && j->n_colsum >= 0 && j->n_colsum <= AGX_MAX_LAYERS, "agx_small_grads: bad job list");
   int blocks = 0;
+  agx::TnJobs tj;
+  tj.n = 0;
+  if (tn) {
+    AGX_CHECK_ARG(tn->n >= 0 && tn->n <= AGX_MAX_LAYERS, "agx_small_grads: bad product list");
+    tj = *tn;
+    for (int q = 0; q < tj.n; ++q) {
+      const agx::TnJobs::Job &t = tj.job[q];
+      AGX_CHECK_ARG(t.A && t.B && t.C && t.M > 0 && t.N > 0 && t.K > 0 && t.lda >= t.M && t.ldb >= t.N && t.ldc >= t.N &&
+                        agx::tn_job_ok(t.M, t.N, t.K), "agx_small_grads: product job %d", q);
+      blocks += agx::cdiv(agx::cdiv(t.M, 32) * agx::cdiv(t.N, 32), 4);
+    }
+  }
   for (int c = 0; c < j->n_colsum; ++c) {
     AGX_CHECK_ARG(j->cs_A[c] && j->cs_out[c] && j->cs_lda[c] >= j->cs_H[c] && j->cs_r0[c] >= 0 &&
                       j->cs_r1[c] >= j->cs_r0[c] && j->cs_H[c] > 0, "agx_small_grads: colsum job %d", c);
@@ -1123,7 +1190,7 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
   }
   if (blocks == 0) return AGX_OK;
   AGX_CHECK_ARG(!lc.dst_slot || (j->l_losses && lc.src && lc.n >= 0), "agx_small_grads: loss snapshot without a loss job");
-  hipLaunchKernelGGL(small_grads_kernel, dim3(blocks), dim3(1024), 0, agx::as_stream(stream), *j, lc);
+  hipLaunchKernelGGL(small_grads_kernel, dim3(blocks), dim3(1024), 0, agx::as_stream(stream), *j, lc, tj);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
