@@ -25,6 +25,17 @@ struct FusedOpt {
   float *rest_w = nullptr, *rest_s1 = nullptr;
   const float *rest_g = nullptr;
   int64_t rest_n = 0, rest_hole_lo = 0, rest_hole_hi = 0;
+  // optional (needs rest_n > 0): the same launch also prepares the NEXT step's stacked critic input in
+  // another buffer - copy workgroups behind the update workgroups move nx_rows generated rows (G columns)
+  // from nx_src to nx_dst, and update workgroup 0, which owns the embedding tables (flat offsets < 1024),
+  // writes the covariate columns [G, G+ncov) of rows [0, nx_cov_rows) of nx_cov from the tables it has just
+  // updated: [num[r % nx_B] | emb_0[cat[r % nx_B, 0]] | ...] like agx_stack_rows
+  const float *nx_src = nullptr;
+  float *nx_dst = nullptr, *nx_cov = nullptr;
+  int nx_lds = 0, nx_ldd = 0, nx_rows = 0, nx_G = 0, nx_cov_rows = 0, nx_B = 0, nx_nnum = 0, nx_ldcat = 0;
+  const float *nx_num = nullptr;
+  const int32_t *nx_cat = nullptr;
+  agx_embed_t nx_emb = {};
 };
 // raw_slabs != NULL: no reduce launch; the split-K partial slabs stay in g->ws as [M][splitk][N]
 // (also when splitk == 1) and *raw_slabs receives splitk - the caller's kernel finishes the product
@@ -84,7 +95,8 @@ struct LrTable {
   int n;
   float v[64];
 };
-int iter_stage(void *stream, const float *x, int ldxs, float *X, int ldx, int G, int B, const int32_t *cat,
+// (X2: optional second stacked-input buffer that receives the same real rows)
+int iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2, int ldx, int G, int B, const int32_t *cat,
                int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
                uint64_t rng_offset, float **loss_slot, float *losses_out, const LrTable *lrs, float *lr_dev);
 // Adam with the bias-corrected step size read from device memory (captured iterations)

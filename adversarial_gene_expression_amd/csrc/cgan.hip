@@ -714,11 +714,29 @@ struct agx_iter_graph {
   int64_t draws = 0;
   bool snap = false;   // the last step snapshots the loss log to the address staged per launch
   bool adam = false;
+  bool chainx = false; // real rows are staged into both stacked-input buffers (chain_input)
   agx::LrTable lrs;    // Adam: step sizes for the next replay (agx_cgan_iter_set_lr)
 };
 
 namespace {
 inline uint64_t r4u(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
+
+// One-GPU RMSprop iteration without augmentation whose critic products carry the flat update: the
+// layer-1 product of step k also assembles step k+1's stacked input in the OTHER stacked-input buffer
+// (generated rows + covariate columns from the freshly updated tables), so only step 0 keeps its
+// stack_rows launch.  Real rows are staged into both buffers.  Must agree between the stage call and
+// record_iteration: both ask here.
+bool chain_input(const agx_cgan *h, const agx_iter_args_t *a) {
+  static const bool off = getenv("AGX_NO_CHAIN_INPUT") != nullptr;
+  const agx_mlp_desc_t &dm = h->cfg.disc;
+  if (off || a->split || a->opt_kind != 0 || a->nb_critic < 1 || a->aug_mask_disc || a->aug_mask_gen) return false;
+  if (a->B >= dbl_min() || a->B >= side_min() || getenv("AGX_NO_FUSED_OPT") || getenv("AGX_NO_FUSED_REST")) return false;
+  if (h->ldsx % 4 != 0 || h->ldx % 4 != 0) return false;
+  int64_t emb_end = 0;
+  for (int i = 0; i < dm.emb.n_cat; ++i)
+    emb_end = std::max<int64_t>(emb_end, dm.emb.table_off[i] + (int64_t)dm.emb.vocab[i] * dm.emb.edim[i]);
+  return emb_end <= 1024 && emb_end <= dm.w_off[0];
+}
 
 // Records segment `seg` of the iteration (seg < 0: the whole iteration).  Segments end where a
 // data-parallel run all-reduces a gradient buffer:
@@ -794,7 +812,9 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   // Large batches use two stacked-input buffers alternately: while step k works on one, a side
   // stream assembles step k+1's fake rows (a 2*B*G*4-byte copy) in the other, beside step k's kernels.
   const bool dbl = B >= dbl_min() && !agx_prof_enabled();
-  float *Xb[2] = {h->Xbuf[0], dbl ? h->Xbuf[1] : h->Xbuf[0]};
+  // chained input assembly (see chain_input): needs the critic product to carry the flat update
+  const bool chainx = seg < 0 && fuse_d && rest_d && !dbl && chain_input(h, a);
+  float *Xb[2] = {h->Xbuf[0], (dbl || chainx) ? h->Xbuf[1] : h->Xbuf[0]};
   struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; } } restore{h};
   // fake rows of step k (k == nbc: the generator step's rows [0,B)) into buffer k&1; with_cov: also
   // the covariate columns of the step's rows from the CURRENT embedding tables (same launch)
@@ -824,13 +844,24 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     if (in_seg(k)) {
       // covariate columns of [real; fake] from the CURRENT (just updated) embedding tables
       if (dbl) AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, 2 * B, B));
-      else AGX_TRY(place_fake(k, st, true));
+      else if (!chainx || k == 0) AGX_TRY(place_fake(k, st, true));
       if (dbl) {   // next step's rows on a side stream; critic_core's own fork/join of aux[1] joins it
         AGX_TRY(fork_to(h, st, 1));
         AGX_TRY(place_fake(k + 1, h->aux[1]));
       }
+      agx::FusedOpt dk = dfo;
+      if (chainx) {   // step k+1's rows (the generator step's rows [0,B) when k+1 == nbc) into the other buffer
+        const bool gnext = (k + 1 == nbc);
+        float *Xn = Xb[(k + 1) & 1];
+        dk.nx_src = h->F + (size_t)(k + 1) * B * h->ldsx; dk.nx_lds = h->ldsx;
+        dk.nx_dst = Xn + (gnext ? 0 : (size_t)B * h->ldx); dk.nx_ldd = h->ldx;
+        dk.nx_rows = B; dk.nx_G = G;
+        dk.nx_cov = Xn; dk.nx_cov_rows = gnext ? B : 2 * B; dk.nx_B = B;
+        dk.nx_num = h->snum; dk.nx_nnum = dm.n_num; dk.nx_cat = h->scat; dk.nx_ldcat = dm.emb.n_cat;
+        dk.nx_emb = dm.emb;
+      }
       AGX_TRY(critic_core(h, st, h->scat, B, Bg, h->abuf + (size_t)k * B, a->gp_weight,
-                          a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dfo : nullptr));
+                          a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dk : nullptr));
     }
     if (in_seg(k + 1)) {
       if (adam) AGX_TRY(agx::opt_adam_dev_lr(st, h->dp, h->dg, a->disc_m, a->disc_v, dm.n_flat, h->lrdev + k, a->beta1, a->beta2, a->eps));
@@ -841,7 +872,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   }
   h->X = Xb[nbc & 1];
   if (in_seg(nbc)) {
-    if (!dbl || nbc == 0) AGX_TRY(place_fake(nbc, st, true));
+    if (chainx) {}   // assembled by the last critic step's layer-1 product
+    else if (!dbl || nbc == 0) AGX_TRY(place_fake(nbc, st, true));
     else AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));
     AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc,
                      fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));
@@ -882,6 +914,7 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   g->h = h; g->B = a->B; g->nb_critic = a->nb_critic;
   g->snap = !a->split && !a->disc_losses && !a->gen_losses;
   g->adam = a->opt_kind == 1;
+  g->chainx = chain_input(h, a);
   g->lrs.n = 0;
   const int nseg = a->split ? a->nb_critic + 2 : 1;
   for (int s = 0; s < nseg; ++s) {
@@ -927,7 +960,7 @@ extern "C" int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const floa
     agx::set_error("agx_cgan_iter_stage: Adam iteration needs agx_cgan_iter_set_lr(%d values) first", g->nb_critic + 1);
     return AGX_E_STATE;
   }
-  return agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum, B * nnum,
+  return agx::iter_stage(st, x, ldx, h->Xbuf[0], g->chainx ? h->Xbuf[1] : nullptr, h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum, B * nnum,
                          h->rngpos, rng_offset, h->loss_slot, nullptr, g->adam ? &g->lrs : nullptr, h->lrdev);
 }
 
@@ -954,7 +987,7 @@ extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const flo
       agx::set_error("agx_cgan_iter_launch: Adam iteration needs agx_cgan_iter_set_lr(%d values) first", g->nb_critic + 1);
       return AGX_E_STATE;
     }
-    AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum,
+    AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], g->chainx ? h->Xbuf[1] : nullptr, h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum,
                             B * nnum, h->rngpos, rng_offset, h->loss_slot, losses_out, g->adam ? &g->lrs : nullptr,
                             h->lrdev));
     for (int s = 0; s < g->nseg; ++s) AGX_HIP(hipGraphLaunch(g->exec[s], st));
@@ -998,7 +1031,7 @@ extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_a
   AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_eager: covariates missing");
   hipStream_t st = agx::as_stream(stream);
   const bool snap = !a->disc_losses && !a->gen_losses;
-  AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], h->ldx, h->G, a->B, cat, h->scat, a->B * ncat, num, h->snum,
+  AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], chain_input(h, a) ? h->Xbuf[1] : nullptr, h->ldx, h->G, a->B, cat, h->scat, a->B * ncat, num, h->snum,
                           a->B * nnum, h->rngpos, rng_offset, h->loss_slot, snap ? losses_out : nullptr,
                           lrs.n ? &lrs : nullptr, h->lrdev));
   int64_t draws = 0;

@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
 // One launch in front of a replayed iteration: real rows -> rows [0,B) of the stacked critic input,
 // covariates -> staging, RNG stream position and the loss-snapshot address -> device memory.
 __global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict__ x, int ldxs,
-                                                         float *__restrict__ X, int ldx, int G, int vec,
+                                                         float *__restrict__ X, float *__restrict__ X2, int ldx, int G, int vec,
                                                          const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
                                                          const float *__restrict__ num, float *__restrict__ snum, int n_num,
                                                          unsigned long long *rngpos, unsigned long long rng_offset,
@@ -827,14 +827,24 @@ __global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict
   const int b = blockIdx.y;
   const float *s = x + (size_t)b * ldxs;
   float *d = X + (size_t)b * ldx;
+  float *d2 = X2 ? X2 + (size_t)b * ldx : nullptr;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   if (vec) {
     const int g4 = G >> 2;
-    for (int q = t0; q < g4; q += stride)
-      reinterpret_cast<float4 *>(d)[q] = reinterpret_cast<const float4 *>(s)[q];
-    for (int g = (g4 << 2) + t0; g < G; g += stride) d[g] = s[g];
+    for (int q = t0; q < g4; q += stride) {
+      const float4 v = reinterpret_cast<const float4 *>(s)[q];
+      reinterpret_cast<float4 *>(d)[q] = v;
+      if (d2) reinterpret_cast<float4 *>(d2)[q] = v;
+    }
+    for (int g = (g4 << 2) + t0; g < G; g += stride) {
+      d[g] = s[g];
+      if (d2) d2[g] = s[g];
+    }
   } else {
-    for (int g = t0; g < G; g += stride) d[g] = s[g];
+    for (int g = t0; g < G; g += stride) {
+      d[g] = s[g];
+      if (d2) d2[g] = s[g];
+    }
   }
   if (blockIdx.x == 0 && b == 0) {
     for (int i = threadIdx.x; i < n_cat; i += blockDim.x) scat[i] = cat[i];
@@ -1195,14 +1205,14 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
   return AGX_OK;
 }
 
-int agx::iter_stage(void *stream, const float *x, int ldxs, float *X, int ldx, int G, int B, const int32_t *cat,
+int agx::iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2, int ldx, int G, int B, const int32_t *cat,
                     int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
                     uint64_t rng_offset, float **loss_slot, float *losses_out, const agx::LrTable *lrs, float *lr_dev) {
   agx::LrTable none;
   none.n = 0;
-  const int vec = agx::aligned16(x) && agx::aligned16(X) && ldxs % 4 == 0 && ldx % 4 == 0;
+  const int vec = agx::aligned16(x) && agx::aligned16(X) && (!X2 || agx::aligned16(X2)) && ldxs % 4 == 0 && ldx % 4 == 0;
   const int gx = std::max(1, std::min(8, agx::cdiv(G, 4 * 256)));
-  hipLaunchKernelGGL(iter_stage_kernel, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, ldx, G, vec,
+  hipLaunchKernelGGL(iter_stage_kernel, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, X2, ldx, G, vec,
                      cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
                      (unsigned long long)rng_offset, loss_slot, losses_out, (lrs && lr_dev) ? *lrs : none, lr_dev);
   AGX_LAUNCH_CHECK();

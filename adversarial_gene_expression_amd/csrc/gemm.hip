@@ -64,6 +64,15 @@ struct KParams {
   float *rest_w, *rest_s1;
   const float *rest_g;
   long long rest_n, rest_hole_lo4, rest_hole_len4;
+  // ... and the next step's stacked critic input (FusedOpt::nx_*): copy workgroups behind the update
+  // workgroups, covariate columns by update workgroup 0
+  int opt_copy_blocks;
+  const float *nx_src;
+  float *nx_dst, *nx_cov;
+  int nx_lds, nx_ldd, nx_rows, nx_G, nx_cov_rows, nx_B, nx_nnum, nx_ldcat;
+  const float *nx_num;
+  const int *nx_cat;
+  agx_embed_t nx_emb;
   // SYRK only
   long long tile_begin;
   int tiles_1d;
@@ -120,6 +129,50 @@ __device__ __forceinline__ void rest_rmsprop(const KParams &p, int blk, int nblk
     const float r = rho * p.rest_s1[i] + omr * (gg * gg);
     p.rest_s1[i] = r;
     p.rest_w[i] = p.rest_w[i] - lr * gg / (sqrtf(r) + eps);
+  }
+}
+
+// generated rows of the next step -> its stacked input (gene columns), by copy workgroup blk of nblk
+__device__ __forceinline__ void next_copy(const KParams &p, int blk, int nblk) {
+  const int g4 = p.nx_G >> 2, tail = p.nx_G & 3, per_row = g4 + (tail ? 1 : 0);
+  const long long total = (long long)p.nx_rows * per_row;
+  for (long long q = (long long)blk * blockDim.x + threadIdx.x; q < total; q += (long long)nblk * blockDim.x) {
+    const int r = (int)(q / per_row), c = (int)(q % per_row);
+    const float *s = p.nx_src + (size_t)r * p.nx_lds + 4 * c;
+    float *d = p.nx_dst + (size_t)r * p.nx_ldd + 4 * c;
+    if (c < g4) {
+      *reinterpret_cast<float4 *>(d) = *reinterpret_cast<const float4 *>(s);
+    } else {
+      for (int e = 0; e < tail; ++e) d[e] = s[e];
+    }
+  }
+}
+
+// covariate columns of the next step's rows from the embedding tables this workgroup has just updated
+// (same values as stack_rows_kernel writes: [num | emb_0 | emb_1 ...] of source row r % B)
+__device__ __forceinline__ void next_cov(const KParams &p) {
+  int ncov = p.nx_nnum;
+  for (int i = 0; i < p.nx_emb.n_cat; ++i) ncov += p.nx_emb.edim[i];
+  const int total = p.nx_cov_rows * ncov;
+  const volatile float *tables = p.rest_w;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int r = idx / ncov, b = r % p.nx_B;
+    int c = idx % ncov;
+    float v = 0.f;
+    if (c < p.nx_nnum) {
+      v = p.nx_num[(size_t)b * p.nx_nnum + c];
+    } else {
+      c -= p.nx_nnum;
+      for (int i = 0; i < p.nx_emb.n_cat; ++i) {
+        if (c < p.nx_emb.edim[i]) {
+          const int row = p.nx_cat[(size_t)b * p.nx_ldcat + i];
+          if (row >= 0 && row < p.nx_emb.vocab[i]) v = tables[p.nx_emb.table_off[i] + (size_t)row * p.nx_emb.edim[i] + c];
+          break;
+        }
+        c -= p.nx_emb.edim[i];
+      }
+    }
+    p.nx_cov[(size_t)r * p.nx_ldd + p.nx_G + idx % ncov] = v;
   }
 }
 
@@ -407,7 +460,17 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   const int l31 = lane & 31, lh = lane >> 5;
 
   if (OPT && p.rest_n > 0 && (int)blockIdx.x >= p.opt_tiles) {
-    rest_rmsprop(p, (int)blockIdx.x - p.opt_tiles, (int)gridDim.x - p.opt_tiles);
+    const int rb = (int)blockIdx.x - p.opt_tiles;
+    if (rb < p.opt_rest_blocks) {
+      rest_rmsprop(p, rb, p.opt_rest_blocks);
+      if (rb == 0 && p.nx_cov) {   // the tables (flat offsets < 1024) were updated by this workgroup's first pass
+        __threadfence_block();
+        __syncthreads();
+        next_cov(p);
+      }
+    } else {
+      next_copy(p, rb - p.opt_rest_blocks, p.opt_copy_blocks);
+    }
     return;
   }
   // tiles of the product (an OPT launch without split-K may carry extra update workgroups behind them)
@@ -1026,7 +1089,7 @@ int launch(hipStream_t st, const KParams &p, int tiles) {
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
   auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT>;  // LDS limit raised in agx_init
-  dim3 grid(tiles + ((OPT && p.rest_n > 0) ? p.opt_rest_blocks : 0), p.splitk, 1), block(WM * WN * 64, 1, 1);
+  dim3 grid(tiles + ((OPT && p.rest_n > 0) ? p.opt_rest_blocks + p.opt_copy_blocks : 0), p.splitk, 1), block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
@@ -1235,6 +1298,23 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
       p.rest_hole_len4 = (fo->rest_hole_hi - fo->rest_hole_lo) / 4;
       const int64_t rest4 = (fo->rest_n >> 2) - p.rest_hole_len4;
       p.opt_rest_blocks = (int)std::min<int64_t>(256, std::max<int64_t>(1, agx::cdiv64(rest4 + 256, 256)));
+      if (fo->nx_cov || fo->nx_dst) {
+        int64_t emb_end = 0;
+        for (int i = 0; i < fo->nx_emb.n_cat; ++i)
+          emb_end = std::max<int64_t>(emb_end, fo->nx_emb.table_off[i] + (int64_t)fo->nx_emb.vocab[i] * fo->nx_emb.edim[i]);
+        AGX_CHECK_ARG(fo->nx_src && fo->nx_dst && fo->nx_cov && fo->nx_rows > 0 && fo->nx_G > 0 && fo->nx_lds >= fo->nx_G &&
+                          fo->nx_ldd >= fo->nx_G && fo->nx_lds % 4 == 0 && fo->nx_ldd % 4 == 0 && agx::aligned16(fo->nx_src) &&
+                          agx::aligned16(fo->nx_dst) && fo->nx_B > 0 && fo->nx_cov_rows >= 0 && fo->nx_emb.n_cat >= 0 &&
+                          fo->nx_emb.n_cat <= AGX_MAX_CAT && (fo->nx_emb.n_cat == 0 || fo->nx_cat) &&
+                          (fo->nx_nnum == 0 || fo->nx_num) && emb_end <= 1024 && emb_end <= fo->rest_hole_lo &&
+                          true,
+                      "agx_gemm_f32: bad next-input description of the fused optimizer");
+        p.nx_src = fo->nx_src; p.nx_dst = fo->nx_dst; p.nx_cov = fo->nx_cov;
+        p.nx_lds = fo->nx_lds; p.nx_ldd = fo->nx_ldd; p.nx_rows = fo->nx_rows; p.nx_G = fo->nx_G;
+        p.nx_cov_rows = fo->nx_cov_rows; p.nx_B = fo->nx_B; p.nx_nnum = fo->nx_nnum; p.nx_ldcat = fo->nx_ldcat;
+        p.nx_num = fo->nx_num; p.nx_cat = fo->nx_cat; p.nx_emb = fo->nx_emb;
+        p.opt_copy_blocks = (int)std::min<int64_t>(128, std::max<int64_t>(1, agx::cdiv64((int64_t)fo->nx_rows * (fo->nx_G / 4 + 1), 4 * 256)));
+      }
     }
   }
   Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk, g->ws ? g->ws_floats : 0,
@@ -1277,7 +1357,8 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   agx::ProfScope prof(st, g->prof_tagged ? g->prof_id : AGX_K_GEMM_UNTAGGED,
                       2.0 * g->M * (double)g->N * g->K,
                       4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N) +
-                          (opt ? 12.0 * (double)p.opt_rows * g->N : 0.0));
+                          (opt ? 12.0 * (double)p.opt_rows * g->N : 0.0) +
+                          (p.opt_copy_blocks ? 8.0 * (double)p.nx_rows * p.nx_G : 0.0));
   p.opt_tiles = pl.tiles;
   int rc;
   if (opt && pl.cfg == 0)
