@@ -115,9 +115,25 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
     if (j < p.H2) {
       const int kq = (p.H1 + 3) >> 2;
       const int k0 = q * kq, k1 = min(p.H1, k0 + kq);
-      const float *w = p.W2 + (size_t)k0 * p.ldw2 + j;
-#pragma unroll 8
-      for (int k = k0; k < k1; ++k) {
+      const float *__restrict__ w = p.W2 + (size_t)k0 * p.ldw2 + j;
+      int k = k0;
+      // 16 weight loads in flight per thread: the k loop is a chain of L2 round trips, not arithmetic
+      // (batches of 8 took 8 round trips per quarter of a 256-wide layer)
+      for (; k + 16 <= k1; k += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)u * p.ldw2];
+        w += (size_t)16 * p.ldw2;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float4 av = a1[k + u];
+          acc[0] = fmaf(av.x, wv[u], acc[0]);
+          acc[1] = fmaf(av.y, wv[u], acc[1]);
+          acc[2] = fmaf(av.z, wv[u], acc[2]);
+          acc[3] = fmaf(av.w, wv[u], acc[3]);
+        }
+      }
+      for (; k < k1; ++k) {
         const float wv = *w;
         w += p.ldw2;
         const float4 av = a1[k];

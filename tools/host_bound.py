@@ -14,9 +14,14 @@ disc = T.Critic(G, V, n_num, H, 1, seed=2)
 gopt, dopt = T.RMSprop(5e-4), T.RMSprop(5e-4)
 x, cc, nc = bench.synthetic_batch_pool(G, V, n_num, B * 8, seed=100)
 T.set_seed(1000)
+EAGER = bool(os.environ.get('HB_EAGER'))   # the same launch sequence queued directly (no graph)
 def it(i):
     s = slice((i % 8) * B, (i % 8 + 1) * B)
-    T.train_iteration(x[s], cc[s], nc[s], gen, disc, gopt, dopt, 5)
+    if EAGER:
+        pair = T._pair(gen, disc, B, 6)
+        T._rng.offset += pair.iteration_eager(x[s], cc[s], nc[s], gen, disc, gopt, dopt, 5, 10.0, T._rng.seed, T._rng.offset)
+    else:
+        T.train_iteration(x[s], cc[s], nc[s], gen, disc, gopt, dopt, 5)
 for i in range(30): it(i)
 torch.cuda.synchronize()
 n = 300
