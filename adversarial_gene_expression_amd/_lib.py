@@ -148,6 +148,7 @@ SIGNATURES = {
     'agx_prof_read': (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'agx_prof_name': (C.c_char_p, [_i32]),
     'agx_prof_spin': (C.c_int, [_vp, _i32]),
+    'agx_prof_empty_bracket_us': (C.c_int, [_vp, _i32, C.POINTER(C.c_double)]),
     'agx_prof_enabled': (C.c_int, []),
     'agx_prof_clock': (C.c_int, [_vp, _i32, _i32, _vp]),
     'agx_sizeof': (_i64, [_i32]),

@@ -108,6 +108,30 @@ extern "C" int agx_prof_spin(void *stream, int32_t microseconds) {
   return AGX_OK;
 }
 
+// Mean elapsed time of n EMPTY brackets (start and stop recorded back to back on the stream, queued
+// behind a busy-wait like the measured ones): what a bracket adds to the launch it encloses.
+extern "C" int agx_prof_empty_bracket_us(void *stream, int32_t n, double *mean_us) {
+  AGX_CHECK_ARG(n > 0 && n <= 1024 && mean_us, "agx_prof_empty_bracket_us: bad argument");
+  hipStream_t st = agx::as_stream(stream);
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  for (auto &e : ev) AGX_HIP(hipEventCreate(&e));
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, 2000ull * 100ull);
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventRecord(ev[2 * i], st);
+    (void)hipEventRecord(ev[2 * i + 1], st);
+  }
+  AGX_HIP(hipStreamSynchronize(st));
+  double tot = 0;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0;
+    AGX_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    tot += ms;
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  *mean_us = tot / n * 1e3;
+  return AGX_OK;
+}
+
 extern "C" int agx_prof_enable(int32_t filter) {
   AGX_CHECK_ARG(filter >= -2 && filter < AGX_K_COUNT, "agx_prof_enable: bad filter %d", filter);
   g_filter = filter;

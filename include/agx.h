@@ -68,6 +68,9 @@ const char *agx_prof_name(int32_t id);
  * NOT usable inside a captured graph (ROCm 7.2 rejects hipEventElapsedTime on graph-recorded
  * events): agx_cgan_iter_capture refuses to capture while profiling is enabled.            */
 int agx_prof_spin(void *stream, int32_t microseconds);
+/* mean elapsed time (us) of n empty brackets on the stream: the part of a bracketed duration that
+ * the two event records add (bench.py reports its roofline duration with this subtracted) */
+int agx_prof_empty_bracket_us(void *stream, int32_t n, double *mean_us);
 int agx_prof_enabled(void);
 /* Clock probe: out_dev[0] = shader MHz seen by a kernel of `blocks` x 4 waves issuing `mfmas`
  * dependent 32x32x2 fp32 MFMAs each, out_dev[1] = cycles per MFMA (measurement only). */
