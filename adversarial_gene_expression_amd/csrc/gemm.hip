@@ -851,9 +851,10 @@ __device__ __forceinline__ int frag_lane_off(int ld, int i, int h) {
   return KC ? i * ld + 4 * h : 4 * h * ld + i;
 }
 
-template <bool TA, bool TB, bool VEC, int U>
-__global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
-  __shared__ float red[4][32][33];
+// NW = 8 (long K ranges): two waves per SIMD, so one wave's loads are in flight while the other's MFMAs issue
+template <bool TA, bool TB, bool VEC, int U, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
+  __shared__ float red[NW][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + 31) / 32;
@@ -874,7 +875,7 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
   if (m0 + 32 <= p.M && n0 + 32 <= p.N) {  // interior tile: full k-groups without clamps or masks
     const int nfull = (kend - kbeg) / 8;
     const int la = frag_lane_off<!TA>(p.lda, i, h), lb = frag_lane_off<TB>(p.ldb, i, h);
-    for (; g0 + U <= nfull; g0 += 4 * U) {
+    for (; g0 + U <= nfull; g0 += NW * U) {
       float av[U][4], bv[U][4];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -889,7 +890,7 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
     }
   }
-  for (; g0 < ngroups; g0 += 4 * U) {
+  for (; g0 < ngroups; g0 += NW * U) {
     float av[U][4], bv[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -908,23 +909,26 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const KParams p) {
   __syncthreads();
   {
     const int cc = tid & 31, col = n0 + cc;
-    int rows[4];
-    float v[4];
+    constexpr int NQ = 16 / NW;   // rows per thread: 32 rows over NW*2 thread rows
+    int rows[NQ];
+    float v[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rr = (tid >> 5) + 8 * q;
+    for (int q = 0; q < NQ; ++q) {
+      const int rr = (tid >> 5) + 2 * NW * q;
       rows[q] = m0 + rr;
-      v[q] = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc];
+      float t = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc];
+      if (NW == 8) t += red[4][rr][cc] + red[5][rr][cc] + red[6][rr][cc] + red[7][rr][cc];
+      v[q] = t;
     }
     if (p.to_ws) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NQ; ++q)
         if (rows[q] < p.M && col < p.N) p.ws[slab_off(p, z, rows[q]) + col] = v[q];
     } else {
-      epilogue_column<4>(p, rows, col, v);
+      epilogue_column<NQ>(p, rows, col, v);
       if (p.rowsq) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           const float sq = half_wave_sum_at31(v[q] * v[q]);
           if (cc == 31 && rows[q] < p.M) p.rowsq[(size_t)rows[q] * p.rowsq_ld + (col >> 5)] = sq;
         }
@@ -1067,6 +1071,17 @@ int launch_wave(hipStream_t st, const KParams &p, bool vec, int tm, int tn) {
 template <bool TA, bool TB>
 int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int groups_per_wave) {
   dim3 grid(tiles, p.splitk, 1), block(256, 1, 1);
+  // long K range per workgroup (the 18k-gene first-layer products at batch 32): 8 waves share it
+  static const int nw8_min = getenv("AGX_DIRECT_NW8_MIN") ? atoi(getenv("AGX_DIRECT_NW8_MIN")) : 200;
+  if (std::min(p.kchunk, p.K) >= nw8_min) {
+    // (8 k-groups per wave per pass whatever the range: balancing the passes over the waves - 144 groups as
+    // 3 x 6 per wave instead of 64 + 64 + 16 - measured 5 us per iteration SLOWER; 16 waves: no gain)
+    dim3 block8(512, 1, 1);
+    if (vec) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, true, 8, 8>), grid, block8, 0, st, p);
+    else hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, false, 8, 8>), grid, block8, 0, st, p);
+    AGX_LAUNCH_CHECK();
+    return AGX_OK;
+  }
 #define AGX_DIRECT(V, UU) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, V, UU>), grid, block, 0, st, p)
 #define AGX_DIRECT_U(V)                         \
   do {                                          \
@@ -1190,7 +1205,8 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
       if (K > 512) {
         // (with the tail kernels reducing the slabs, 2 or 3 workgroups per CU still lose: the product
         // gains 4-7 us per iteration, the tails lose 10-35)
-        sk = std::min(agx::cdiv(K, 128), agx::cdiv(cus, pl.tiles));
+        static const double mult = getenv("AGX_DIRECT_SK_MULT") ? atof(getenv("AGX_DIRECT_SK_MULT")) : 1.0;
+        sk = std::min(agx::cdiv(K, 128), agx::cdiv((int)(cus * mult), pl.tiles));
         if (sk > agx::cdiv(K, 128)) sk = agx::cdiv(K, 128);
       }
     } else {
