@@ -603,6 +603,20 @@ __device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile
   }
 }
 
+// dE_i[rowid, d] = s . W[coff + d, :] for every d at once: one wave per embedding dimension (the d loop
+// with a block-wide reduction per d was a chain of edim dependent round trips: the launch's long pole)
+__device__ __forceinline__ void emb_dots(const agx_small_grads_t &j, int i, int rowid, int coff,
+                                         const float *sfin, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int d = wave; d < j.emb.edim[i]; d += 16) {
+    const float *__restrict__ w = j.emb_W + (size_t)(coff + d) * j.emb_ldw;
+    float v = 0.f;
+    for (int k = lane; k < H; k += 64) v += sfin[k] * w[k];
+    v = agx::wave_sum(v);
+    if (lane == 0) j.emb_grad[j.emb.table_off[i] + (size_t)rowid * j.emb.edim[i] + d] = v;
+  }
+}
+
 __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j, const agx::LossCopy lc,
                                                            const agx::TnJobs tn) {
   __shared__ float red[16][64];
@@ -647,7 +661,6 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
         ++i;
       }
       const int H = j.emb_H;
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       float *part = svec, *sfin = H <= 512 ? svec + 1024 : svec;
       // s[k] = sum over the matching rows of D[r,k]; narrow layers split the rows over 1024/Hp
       // thread groups whose partials meet in LDS in a fixed order
@@ -699,20 +712,7 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
           sfin4[threadIdx.x] = t;
         }
         __syncthreads();
-        for (int d = 0; d < j.emb.edim[i]; ++d) {
-          const float *w = j.emb_W + (size_t)(coff + d) * j.emb_ldw;
-          float v = 0.f;
-          for (int k = threadIdx.x; k < H; k += 1024) v += sfin4[k] * w[k];
-          v = wave_sum(v);
-          if (lane == 0) red[0][wave] = v;
-          __syncthreads();
-          if (threadIdx.x == 0) {
-            float t = 0.f;
-            for (int w16 = 0; w16 < 16; ++w16) t += red[0][w16];
-            j.emb_grad[j.emb.table_off[i] + (size_t)rowid * j.emb.edim[i] + d] = t;
-          }
-          __syncthreads();
-        }
+        emb_dots(j, i, rowid, coff, sfin4, H);
         return;
       }
       for (int c0 = 0; c0 < j.emb_rows || c0 == 0; c0 += 2048) {
@@ -765,20 +765,7 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
       }
       __syncthreads();
       // dot with the edim_i kernel rows that the embedding columns feed
-      for (int d = 0; d < j.emb.edim[i]; ++d) {
-        const float *w = j.emb_W + (size_t)(coff + d) * j.emb_ldw;
-        float v = 0.f;
-        for (int k = threadIdx.x; k < H; k += 1024) v += sfin[k] * w[k];
-        v = wave_sum(v);
-        if (lane == 0) red[0][wave] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          float t = 0.f;
-          for (int w16 = 0; w16 < 16; ++w16) t += red[0][w16];
-          j.emb_grad[j.emb.table_off[i] + (size_t)rowid * j.emb.edim[i] + d] = t;
-        }
-        __syncthreads();
-      }
+      emb_dots(j, i, rowid, coff, sfin, H);
       return;
     }
     blk -= rows;

@@ -1077,7 +1077,11 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
     // (8 k-groups per wave per pass whatever the range: balancing the passes over the waves - 144 groups as
     // 3 x 6 per wave instead of 64 + 64 + 16 - measured 5 us per iteration SLOWER; 16 waves: no gain)
     dim3 block8(512, 1, 1);
-    if (vec) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, true, 8, 8>), grid, block8, 0, st, p);
+    static const bool short4 = getenv("AGX_DIRECT8_NO_U4") == nullptr;
+    if (short4 && agx::cdiv(std::min(p.kchunk, p.K), 8) <= 32) {   // <= 4 groups per wave: all 8 waves get work
+      if (vec) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, true, 4, 8>), grid, block8, 0, st, p);
+      else hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, false, 4, 8>), grid, block8, 0, st, p);
+    } else if (vec) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, true, 8, 8>), grid, block8, 0, st, p);
     else hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, false, 8, 8>), grid, block8, 0, st, p);
     AGX_LAUNCH_CHECK();
     return AGX_OK;
