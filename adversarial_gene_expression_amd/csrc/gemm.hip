@@ -917,7 +917,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
       const int rr = (tid >> 5) + 2 * NW * q;
       rows[q] = m0 + rr;
       float t = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc];
-      if (NW == 8) t += red[4][rr][cc] + red[5][rr][cc] + red[6][rr][cc] + red[7][rr][cc];
+      if constexpr (NW == 8) t += red[4][rr][cc] + red[5][rr][cc] + red[6][rr][cc] + red[7][rr][cc];
       v[q] = t;
     }
     if (p.to_ws) {
@@ -1074,7 +1074,7 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
   // long K range per workgroup (the 18k-gene first-layer products at batch 32): 8 waves share it
   static const int nw8_min = getenv("AGX_DIRECT_NW8_MIN") ? atoi(getenv("AGX_DIRECT_NW8_MIN")) : 200;
   if (std::min(p.kchunk, p.K) >= nw8_min) {
-    // (8 k-groups per wave per pass whatever the range: balancing the passes over the waves - 144 groups as
+    // (8 k-groups per wave per pass whatever the range - 9, 12 or 18 in flight: +5..9 us per iteration; balancing the passes over the waves - 144 groups as
     // 3 x 6 per wave instead of 64 + 64 + 16 - measured 5 us per iteration SLOWER; 16 waves: no gain)
     dim3 block8(512, 1, 1);
     static const bool short4 = getenv("AGX_DIRECT8_NO_U4") == nullptr;
