@@ -443,8 +443,10 @@ struct Tile {
 
 using agx::tri_decode;
 
+// OPTI: the fused-optimizer epilogue and its prefetch take a clamp-free path on interior tiles (its own
+// instantiation: compiled into the K = 1536 launches the same source measured 1-2 % SLOWER per iteration)
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, int DBG = 0,
-          bool OPT = false>
+          bool OPT = false, bool OPTI = false>
 __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -509,7 +511,19 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   // (starting each CU's k-th workgroup k * 1.7 us late, to spread the load / multiply / update phases
   // of this one-round grid over time, only added the delay: +4 us per launch per step of delay)
   float pw[OPT_PRE ? 16 : 1], ps[OPT_PRE ? 16 : 1];
-  if (OPT_PRE) {
+  const bool opt_interior = OPT_PRE && OPTI && m0 + BM <= min(p.M, p.opt_rows) && n0 + BN <= p.N;
+  if (opt_interior) {
+    // interior tile: one 64-bit base, 32-bit row offsets, no clamps
+    const size_t base = (size_t)(m0 + wm * 32 + 4 * lh) * p.ldc + (n0 + wn * 32 + l31);
+    const float *__restrict__ wb = p.opt_w + base;
+    const float *__restrict__ sb = p.opt_s1 + base;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ((r & 3) + 8 * (r >> 2)) * p.ldc;
+      pw[r] = wb[o];
+      ps[r] = sb[o];
+    }
+  } else if (OPT_PRE) {
     const int cc = min(n0 + wn * 32 + l31, p.N - 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -571,6 +585,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   int t = 0;
   if (VEC && DBG == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
     // interior tile: K-tiles 1 .. nfull-1 are loaded without clamps and stored without masks
+    // (the first K-tile through the same path: no gain at K = 96, 0.4 % slower at K = 1536)
     const int nfull = (kend - kbeg) / BK;
     int offa[TileA::PT], offb[TileB::PT];
     TileA::lane_offsets(p.lda, tid, offa);
@@ -670,6 +685,21 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (rows[r] < p.M && col < p.N) p.ws[slab_off(p, z, rows[r]) + col] = v[r];
+        } else if (opt_interior) {
+          // interior tile: every element is updated - no per-element bounds tests, one 64-bit base and
+          // 32-bit row offsets (the epilogue's instruction stream is on the launch's critical path: a single
+          // extra branch per element measured +4 us per launch)
+          const float omr = 1.f - p.opt_rho;
+          float *__restrict__ wb = p.opt_w + (size_t)rbase * p.ldc + col;
+          float *__restrict__ sb = p.opt_s1 + (size_t)rbase * p.ldc + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = ((r & 3) + 8 * (r >> 2)) * p.ldc;
+            const float g = v[r] * p.alpha;
+            const float rr = p.opt_rho * ps[r] + omr * (g * g);
+            sb[o] = rr;
+            wb[o] = pw[r] - p.opt_lr * g / (sqrtf(rr) + p.opt_eps);
+          }
         } else if (OPT_PRE) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -1102,25 +1132,27 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
   return AGX_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false,
+          bool OPTI = false>
 int launch(hipStream_t st, const KParams &p, int tiles) {
   using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
-  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT>;  // LDS limit raised in agx_init
+  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT, OPTI>;  // LDS limit raised in agx_init
   dim3 grid(tiles + ((OPT && p.rest_n > 0) ? p.opt_rest_blocks + p.opt_copy_blocks : 0), p.splitk, 1), block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false,
+          bool OPTI = false>
 int prepare_one() {
   using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
   AGX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void *>(gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT>),
+      reinterpret_cast<const void *>(gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT, OPTI>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return AGX_OK;
 }
@@ -1255,6 +1287,8 @@ int gemm_prepare_device() {
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, false, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true, true>()));
   return AGX_OK;
 }
 }  // namespace agx
@@ -1384,6 +1418,9 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   if (opt && pl.cfg == 0)
     rc = vec ? launch<128, 128, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
              : launch<128, 128, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
+  else if (opt && g->K <= 512)   // short K (batch < 128): the epilogue's instruction stream is on the critical path
+    rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 32, true, true>(st, p, pl.tiles)
+             : launch<64, 64, 2, 2, true, false, false, false, 32, true, true>(st, p, pl.tiles);
   else if (opt)
     rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
              : launch<64, 64, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
