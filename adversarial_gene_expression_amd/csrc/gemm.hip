@@ -712,6 +712,18 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
           }
         } else if (OPT) {
           epilogue_column<16, true>(p, rows, col, v);
+        } else if (OPTI && m0 + BM <= p.M && n0 + BN <= p.N && !p.rowscale && !p.addrow && !p.mask &&
+                   !p.accumulate && !p.rowsq) {
+          // interior tile of a plain Dense product (alpha, bias, activation): one base pointer, no clamps
+          const float bias = p.bias ? p.bias[col] : 0.f;
+          float *__restrict__ cb = p.C + (size_t)rbase * p.ldc + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float x = v[r] * p.alpha;
+            if (p.bias) x += bias;
+            if (p.act) x = x > 0.f ? x : x * p.slope;
+            cb[((r & 3) + 8 * (r >> 2)) * p.ldc] = x;
+          }
         } else {
           epilogue_column<16>(p, rows, col, v);
           if (p.rowsq) {  // deterministic per-slab partial of sum_col v^2 (only without split-K)
@@ -1180,6 +1192,11 @@ int launch_layout(hipStream_t st, const KParams &p, int tiles, int ta, int tb, b
              : launch<BM, BN, WM, WN, true, false, false, false, BK>(st, p, tiles);
 }
 
+bool fast_epi() {
+  static const bool v = getenv("AGX_NO_FAST_EPI") == nullptr;
+  return v;
+}
+
 struct Plan {
   int cfg, bm, bn, tiles, splitk, kchunk;
   int wtm, wtn;  // wave-kernel tile (cfg >= 8)
@@ -1288,6 +1305,7 @@ int gemm_prepare_device() {
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, false, false, true, false, 32, false, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true, true>()));
   return AGX_OK;
 }
@@ -1426,6 +1444,8 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
              : launch<64, 64, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
   else if (pl.cfg == 0)
     rc = launch_layout<128, 128, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
+  else if (pl.cfg == 1 && !g->ta && !g->tb && vec && g->K <= 512 && fast_epi())
+    rc = launch<64, 64, 2, 2, false, false, true, false, 32, false, true>(st, p, pl.tiles);
   else if (pl.cfg == 1)
     rc = launch_layout<64, 64, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 2)
