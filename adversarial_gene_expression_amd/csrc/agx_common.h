@@ -60,6 +60,7 @@ struct TailArgs {
   float *slopes, *fscale, *D1; int ldd1;
   float *xcov; int ldx, ncov;
   float coef;
+  int rpw;   // rows per workgroup (set by critic_tail)
 };
 int critic_tail(void *stream, int mode, const TailArgs &a);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused

@@ -14,6 +14,9 @@
 // orders (deterministic).
 #include "agx_common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 using agx::wave_sum;
@@ -31,8 +34,8 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
   const bool interp = MODE == 0 && p.interp_rows > 0;
   const int R = p.interp_rows;
   // slab rows / output rows of this workgroup
-  const int r0 = interp ? (int)blockIdx.x : (int)blockIdx.x * TR;
-  const int nsl = interp ? 2 : min(TR, p.m_slab - r0);
+  const int r0 = interp ? (int)blockIdx.x : (int)blockIdx.x * p.rpw;
+  const int nsl = interp ? 2 : min(p.rpw, p.m_slab - r0);
   const int nout = interp ? 3 : nsl;
   auto srow = [&](int k) { return interp ? r0 + k * R : r0 + k; };
   auto orow = [&](int k) { return interp ? r0 + k * R : p.row0 + r0 + k; };
@@ -174,18 +177,23 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
 
 }  // namespace
 
-int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a) {
+int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
+  agx::TailArgs a = a_in;
   AGX_CHECK_ARG(a.ws && a.splitk >= 1 && a.m_slab >= 1 && a.H1 >= 1 && a.H1 <= TW && a.H2 >= 1 && a.H2 <= TW &&
                     a.W2 && a.ldw2 >= a.H2 && a.A1 && a.A2 && a.lda1 >= a.H1 && a.lda2 >= a.H2,
                 "critic_tail: bad shapes (H1=%d H2=%d m=%d)", a.H1, a.H2, a.m_slab);
   hipStream_t st = agx::as_stream(stream);
+  // rows per workgroup: every workgroup pulls all of W2 (256 KB at 64 B/clk: 1.7 us) whatever its row count, so
+  // few rows are spread over more CUs (their slab traffic per CU shrinks); many rows keep 4 per workgroup
+  static const int small_rpw = getenv("AGX_TAIL_RPW") ? atoi(getenv("AGX_TAIL_RPW")) : 2;
+  a.rpw = (a.interp_rows == 0 && a.m_slab <= 64) ? std::max(1, std::min(TR, small_rpw)) : TR;
   if (mode == 0) {
     AGX_CHECK_ARG(a.b1 && a.b2 && a.w3 && a.b3 && a.D2 && a.out && a.ldd2 >= a.H2 &&
                       (a.interp_rows == 0 || (a.alpha && a.m_slab == 2 * a.interp_rows)),
                   "critic_tail: forward arguments");
     agx::ProfScope prof(st, AGX_K_DISC_FWD_HID, 2.0 * (a.interp_rows ? 3 * a.interp_rows : a.m_slab) * a.H1 * (double)a.H2,
                         4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));
-    const int blocks = a.interp_rows > 0 ? a.interp_rows : agx::cdiv(a.m_slab, TR);
+    const int blocks = a.interp_rows > 0 ? a.interp_rows : agx::cdiv(a.m_slab, a.rpw);
     hipLaunchKernelGGL(critic_tail_kernel<0>, dim3(blocks), dim3(1024), 0, st, a);
   } else {
     AGX_CHECK_ARG(a.rowsq && a.slopes && a.fscale && a.D1 && a.ldd1 >= a.H1 && a.nslab >= 1 && a.rowsq_ld >= a.nslab &&
@@ -193,7 +201,7 @@ int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a) {
                   "critic_tail: second-order arguments");
     agx::ProfScope prof(st, AGX_K_GP2_HID, 2.0 * a.m_slab * a.H1 * (double)a.H2,
                         4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));
-    hipLaunchKernelGGL(critic_tail_kernel<1>, dim3(agx::cdiv(a.m_slab, TR)), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(critic_tail_kernel<1>, dim3(agx::cdiv(a.m_slab, a.rpw)), dim3(1024), 0, st, a);
   }
   AGX_LAUNCH_CHECK();
   return AGX_OK;
