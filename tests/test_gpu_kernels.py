@@ -339,3 +339,15 @@ def test_small_grads_matches_separate_entry_points(gpu, B, H):
     w = -out[:B].astype(np.float64).sum() * inv + out[B:2 * B].astype(np.float64).sum() * inv
     gp = ((slopes.astype(np.float64) - 1) ** 2).sum() * inv
     np.testing.assert_allclose(ls[:3], [w, gp, w + 10 * gp], rtol=1e-5, atol=1e-5)
+
+
+def test_empty_bracket_overhead_is_small_and_positive(gpu):
+    """agx_prof_empty_bracket_us: what the two event records of a bracket add to the launch they
+    enclose (bench.py subtracts it from the bracketed duration of the dominant kernel)."""
+    import ctypes
+    _dev, _lib, lib = _libs()
+    _dev.device()
+    us = ctypes.c_double(-1.0)
+    _lib.check(lib.agx_prof_empty_bracket_us(_dev.stream(), 64, ctypes.byref(us)))
+    assert 0.0 <= us.value < 50.0
+    assert lib.agx_prof_empty_bracket_us(_dev.stream(), 0, ctypes.byref(us)) != 0   # n out of range
