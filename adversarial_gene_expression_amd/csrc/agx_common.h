@@ -100,6 +100,25 @@ struct LrTable {
 int iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2, int ldx, int G, int B, const int32_t *cat,
                int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
                uint64_t rng_offset, float **loss_slot, float *losses_out, const LrTable *lrs, float *lr_dev);
+// All the draws of a captured iteration AND the generator's layer-1 input in ONE launch: segment i fills
+// n values from stream position *base_dev + sub_offset (element skip + j) into out, as rows of `cols` values
+// at leading dimension `ld` when cols > 0 (z straight into the [z | num | emb] rows) and flat otherwise;
+// one more block row writes the covariate columns [zcols, zcols + ncov) of rows [0, rows_cov) of gin0
+// from `tables` ([num | emb_0 | ...] of source row r % B, like agx_stack_rows).
+struct DrawSeg {
+  float *out;
+  int64_t n;
+  uint64_t sub_offset;
+  int64_t skip;
+  int32_t normal, cols, ld;
+};
+struct IterDraws {
+  int n;
+  DrawSeg seg[AGX_MAX_RNG_SEGS];
+};
+int iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const IterDraws &d, const agx_embed_t *e,
+               const float *tables, const float *num, int n_num, const int32_t *cat, int ld_cat, int B, int rows_cov,
+               int zcols, float *gin0, int ldg0);
 // Adam with the bias-corrected step size read from device memory (captured iterations)
 int opt_adam_dev_lr(void *stream, float *w, const float *g, float *m, float *v, int64_t n, const float *lr_dev,
                     float beta1, float beta2, float eps);

@@ -786,7 +786,24 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const bool snap = seg < 0 && !a->split && !a->disc_losses && !a->gen_losses;
   const agx::LossCopy lcopy{h->loss_slot, h->losslog, (nbc + 1) * 4};
   uint64_t sub = 0;
-  {
+  // draws + generator input in one launch (z straight into the [z | num | emb] rows) when the segment list fits
+  static const bool draw_fuse_on = getenv("AGX_NO_DRAW_FUSE") == nullptr;
+  const bool draw_fuse = draw_fuse_on && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS;
+  if (draw_fuse) {
+    agx::IterDraws dr;
+    dr.n = 0;
+    for (int k = 0; k <= nbc; ++k) {
+      dr.seg[dr.n++] = agx::DrawSeg{h->gin0 + (size_t)k * B * h->ldg0, (int64_t)B * Z, sub, (int64_t)lo * Z, 1, Z, h->ldg0};
+      sub += r4u((uint64_t)Bg * Z);
+      if (k < nbc) {
+        dr.seg[dr.n++] = agx::DrawSeg{h->abuf + (size_t)k * B, (int64_t)B, sub, (int64_t)lo, 0, 0, 0};
+        sub += r4u((uint64_t)Bg);
+      }
+    }
+    if (in_seg(0))
+      AGX_TRY(agx::iter_draws(st, a->seed, h->rngpos, dr, &gm0.emb, h->gp, h->snum, gm0.n_num, h->scat, gm0.emb.n_cat, B,
+                              S * B, Z, h->gin0, h->ldg0));
+  } else {
     // every draw of the iteration in one launch (per 16 segments), at the stream positions the eager
     // entry points use for the GLOBAL batch (z_k then alpha_k per critic step, then the generator
     // step's z); a rank keeps rows [lo, lo+B) of each draw
@@ -829,7 +846,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   if (in_seg(0)) {
     // ONE generator forward for all nb_critic+1 z batches (generator weights are constant until the
     // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
-    AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
+    if (!draw_fuse) AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
     AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx));
     // real rows were staged into buffer 0 rows [0,B) (agx_cgan_iter_stage) and stay there for all
     // critic steps (augmentation noise is a trace constant, :210); buffer 1 gets a copy

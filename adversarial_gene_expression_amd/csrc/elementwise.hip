@@ -365,7 +365,7 @@ __global__ void set_u64_kernel(unsigned long long *dst, unsigned long long v) { 
 template <bool NORMAL>
 __device__ __forceinline__ void rng_fill(float *__restrict__ out, long long n, unsigned long long seed,
                                          unsigned long long offset, long long q0, long long qstride,
-                                         long long skip = 0) {
+                                         long long skip = 0, int cols = 0, int ld = 0) {
   // counter block q produces elements 4q .. 4q+3 of the (seed, offset)-keyed stream; out receives
   // elements [skip, skip + n)
   const long long qlo = skip >> 2, nq = (skip + n + 3) >> 2;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void rng_fill(float *__restrict__ out, long long n, u
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const long long j = 4 * q + k - skip;
-      if (j >= 0 && j < n) out[j] = v[k];
+      if (j >= 0 && j < n) out[cols > 0 ? (j / cols) * ld + j % cols : j] = v[k];
     }
   }
 }
@@ -419,6 +419,45 @@ __global__ void __launch_bounds__(256) rng_multi_kernel(const RngSegs segs, unsi
   const long long qs = (long long)gridDim.x * blockDim.x;
   if (sg.normal) rng_fill<true>(sg.out, sg.n, seed, offset, q0, qs, sg.skip);
   else rng_fill<false>(sg.out, sg.n, seed, offset, q0, qs, sg.skip);
+}
+
+// draws of a whole iteration + covariate columns of the generator input (agx::iter_draws)
+__global__ void __launch_bounds__(256) iter_draws_kernel(const agx::IterDraws d, unsigned long long seed,
+                                                         const unsigned long long *__restrict__ base_dev,
+                                                         agx_embed_t e, const float *__restrict__ tables,
+                                                         const float *__restrict__ num, int n_num,
+                                                         const int *__restrict__ cat, int ld_cat, int B, int rows_cov,
+                                                         int zcols, float *__restrict__ gin0, int ldg0, int ncov) {
+  if ((int)blockIdx.y < d.n) {
+    const agx::DrawSeg sg = d.seg[blockIdx.y];
+    const unsigned long long offset = sg.sub_offset + (base_dev ? *base_dev : 0ull);
+    const long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long qs = (long long)gridDim.x * blockDim.x;
+    if (sg.normal) rng_fill<true>(sg.out, sg.n, seed, offset, q0, qs, sg.skip, sg.cols, sg.ld);
+    else rng_fill<false>(sg.out, sg.n, seed, offset, q0, qs, sg.skip, sg.cols, sg.ld);
+    return;
+  }
+  const long long total = (long long)rows_cov * ncov;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / ncov), b = r % B;
+    int c = (int)(idx % ncov);
+    float v = 0.f;
+    if (c < n_num) {
+      v = num[(size_t)b * n_num + c];
+    } else {
+      c -= n_num;
+      for (int i = 0; i < e.n_cat; ++i) {
+        if (c < e.edim[i]) {
+          const int row = cat[(size_t)b * ld_cat + i];
+          if (row >= 0 && row < e.vocab[i]) v = tables[e.table_off[i] + (size_t)row * e.edim[i] + c];
+          break;
+        }
+        c -= e.edim[i];
+      }
+    }
+    gin0[(size_t)r * ldg0 + zcols + (int)(idx % ncov)] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1114,6 +1153,28 @@ extern "C" int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_d
   hipLaunchKernelGGL(rng_multi_kernel, dim3(grid_for((nmax + 3) / 4, 256, 256), n_seg), dim3(256), 0,
                      agx::as_stream(stream), rs, (unsigned long long)seed,
                      (const unsigned long long *)base_dev);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int agx::iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const agx::IterDraws &d, const agx_embed_t *e,
+                    const float *tables, const float *num, int n_num, const int32_t *cat, int ld_cat, int B,
+                    int rows_cov, int zcols, float *gin0, int ldg0) {
+  AGX_CHECK_ARG(d.n > 0 && d.n <= AGX_MAX_RNG_SEGS && e && gin0 && B > 0 && rows_cov >= 0, "iter_draws: bad argument");
+  long long nmax = 0;
+  for (int i = 0; i < d.n; ++i) {
+    AGX_CHECK_ARG(d.seg[i].out && d.seg[i].n >= 0 && d.seg[i].skip >= 0 && (d.seg[i].sub_offset & 3) == 0 &&
+                      (d.seg[i].cols == 0 || d.seg[i].ld >= d.seg[i].cols), "iter_draws: segment %d", i);
+    nmax = std::max<long long>(nmax, d.seg[i].n + 3);
+  }
+  int ncov = n_num;
+  for (int i = 0; i < e->n_cat; ++i) ncov += e->edim[i];
+  AGX_CHECK_ARG(ldg0 >= zcols + ncov && (n_num == 0 || num) && (e->n_cat == 0 || (cat && tables && ld_cat >= e->n_cat)),
+                "iter_draws: generator input description");
+  const int cov_row = (rows_cov > 0 && ncov > 0) ? 1 : 0;
+  hipLaunchKernelGGL(iter_draws_kernel, dim3(grid_for((nmax + 3) / 4, 256, 256), d.n + cov_row), dim3(256), 0,
+                     agx::as_stream(stream), d, (unsigned long long)seed, (const unsigned long long *)base_dev, *e, tables,
+                     num, n_num, cat, ld_cat, B, rows_cov, zcols, gin0, ldg0, ncov);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
