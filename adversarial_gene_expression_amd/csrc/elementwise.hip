@@ -660,6 +660,8 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
                                                            const agx::TnJobs tn) {
   __shared__ float red[16][64];
   __shared__ __attribute__((aligned(16))) float svec[8192];   // [0,6144): partial / final column sums, [6144,8192): row match flags
+  __shared__ int elist[2048];   // matching rows of an embedding-table row (many-row path)
+  __shared__ int wcnt[16];
   int blk = blockIdx.x;
   // blocks in front: the tiny weight-gradient products, 4 tiles per block - one wave per SIMD (16 tiles
   // on one CU queue 4 waves' MFMAs per SIMD: the launch grew from 8.5 to 13 us); waves 4..15 leave
@@ -700,6 +702,7 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
         ++i;
       }
       const int H = j.emb_H;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       float *part = svec, *sfin = H <= 512 ? svec + 1024 : svec;
       // s[k] = sum over the matching rows of D[r,k]; narrow layers split the rows over 1024/Hp
       // thread groups whose partials meet in LDS in a fixed order
@@ -720,24 +723,42 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
           for (int r = threadIdx.x; r < nrow; r += 1024)
             match[r] = j.emb_cat[(size_t)((c0 + r) % j.emb_B) * j.emb_ld_cat + i] == rowid ? 1.f : 0.f;
           __syncthreads();
+          // compact list of the matching rows (ascending), then ONLY those rows are read: a table row matches
+          // about rows / vocab of them, and reading all 2B rows (1 MB at 512 rows per GPU) through one CU per
+          // table row was the launch's long pole (the list keeps the row loop free of dependent index loads)
+          int cnt = 0;
+          for (int base = 0; base < nrow; base += 1024) {
+            const int r = base + (int)threadIdx.x;
+            const bool m = r < nrow && match[r] != 0.f;
+            const unsigned long long bal = __ballot(m);
+            if (lane == 0) wcnt[wave] = __popcll(bal);
+            __syncthreads();
+            int off = cnt, tot = 0;
+            for (int w = 0; w < 16; ++w) {
+              const int cw = wcnt[w];
+              off += w < wave ? cw : 0;
+              tot += cw;
+            }
+            if (m) elist[off + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+            cnt += tot;
+            __syncthreads();
+          }
           if (rg < ng) {
-            int r = rg;
-            for (; r + 7 * ng < nrow; r += 8 * ng) {
-              float4 d[8];
+            int q = rg;
+            for (; q + 3 * ng < cnt; q += 4 * ng) {
+              float4 d[4];
 #pragma unroll
-              for (int u = 0; u < 8; ++u)
-                d[u] = *reinterpret_cast<const float4 *>(j.emb_D + (size_t)(c0 + r + u * ng) * j.emb_ldd + 4 * kk4);
+              for (int u = 0; u < 4; ++u)
+                d[u] = *reinterpret_cast<const float4 *>(j.emb_D + (size_t)(c0 + elist[q + u * ng]) * j.emb_ldd + 4 * kk4);
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                const bool mt = match[r + u * ng] != 0.f;   // select, not multiply: a NaN in another row must not leak
+              for (int u = 0; u < 4; ++u) {
                 float4 &a = (u & 1) ? a1 : a0;
-                a.x += mt ? d[u].x : 0.f; a.y += mt ? d[u].y : 0.f; a.z += mt ? d[u].z : 0.f; a.w += mt ? d[u].w : 0.f;
+                a.x += d[u].x; a.y += d[u].y; a.z += d[u].z; a.w += d[u].w;
               }
             }
-            for (; r < nrow; r += ng) {
-              const float4 d = *reinterpret_cast<const float4 *>(j.emb_D + (size_t)(c0 + r) * j.emb_ldd + 4 * kk4);
-              const bool mt = match[r] != 0.f;
-              a0.x += mt ? d.x : 0.f; a0.y += mt ? d.y : 0.f; a0.z += mt ? d.z : 0.f; a0.w += mt ? d.w : 0.f;
+            for (; q < cnt; q += ng) {
+              const float4 d = *reinterpret_cast<const float4 *>(j.emb_D + (size_t)(c0 + elist[q]) * j.emb_ldd + 4 * kk4);
+              a0.x += d.x; a0.y += d.y; a0.z += d.z; a0.w += d.w;
             }
           }
         }
