@@ -177,3 +177,52 @@ def test_device_resident_scorer_equals_gamma_coef(gpu):
     T.set_seed(9)
     s2 = U.gamma_coef(x, T.predict(cc, nc, gen))
     assert s1 == s2
+
+
+def test_corr_100k_samples_properties(gpu):
+    """BASELINE.json configs[3]: the Pearson matrix of a 100000 x 18154 matrix (fp32 accumulation over
+    K = 100000 samples), through the C-ABI calls bench.py times (agx_colstats, agx_standardize,
+    agx_corr_xtx).  Size-independent properties + a fp64 spot block (utils.py:816-824):
+    bitwise symmetry, |diag - 1| and |r| <= 1 within 5e-5, a 64 x 64 block of random gene pairs within
+    5e-5 of the float64 value (genes carry offsets up to +-5 and scales 0.2..3: centring happens before
+    the product exactly as in the reference)."""
+    import torch
+    from adversarial_gene_expression_amd import _dev, _lib
+    from adversarial_gene_expression_amd._dev import ptr
+    lib = _lib.load()
+    N, G = 100000, 18154
+    ld = _dev.r4(G)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    load = torch.randn(32, ld, device='cuda', generator=gen)
+    shift = (torch.rand(ld, device='cuda', generator=gen) - 0.5) * 10
+    scale = 0.2 + 2.8 * torch.rand(ld, device='cuda', generator=gen)
+    x = torch.empty((N, ld), device='cuda')
+    for r0 in range(0, N, 8192):
+        r1 = min(N, r0 + 8192)
+        f = torch.randn(r1 - r0, 32, device='cuda', generator=gen)
+        x[r0:r1] = (f @ load + 2.0 * torch.randn(r1 - r0, ld, device='cuda', generator=gen)) * scale + shift
+    st = _dev.stream()
+    mean, std = _dev.empty(G), _dev.empty(G)
+    ws = _dev.empty(2 * G, dtype=torch.float64)
+    xs = torch.empty_like(x)
+    c = _dev.empty((G, ld))
+    _lib.check(lib.agx_colstats(st, ptr(x), ld, N, G, ptr(mean), ptr(std), ptr(ws)))
+    _lib.check(lib.agx_standardize(st, ptr(x), ld, N, G, ptr(mean), ptr(std), ptr(xs), ld))
+    _lib.check(lib.agx_corr_xtx(st, ptr(xs), ld, N, G, 1.0 / N, ptr(c), ld, 0, -1))
+    torch.cuda.synchronize()
+    cg = c[:, :G]
+    assert torch.equal(cg, cg.t())
+    diag_err = float((torch.diagonal(cg) - 1).abs().max())
+    idx = torch.randperm(G, device='cuda', generator=gen)[:64]
+    sub = x[:, idx].double()
+    np.testing.assert_allclose(mean[idx].cpu().numpy(), sub.mean(0).cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(std[idx].cpu().numpy(), sub.std(0, unbiased=False).cpu().numpy(), rtol=2e-6)
+    sub = (sub - sub.mean(0)) / sub.std(0, unbiased=False)
+    ref = sub.t() @ sub / N
+    spot_err = float((cg[idx][:, idx].double() - ref).abs().max())
+    print('corr 100000 x 18154: max|diag-1| %.3g, 64x64 spot max|err| %.3g, max|r| %.7f'
+          % (diag_err, spot_err, float(cg.abs().max())))
+    assert float(ref.abs().min()) < 0.05 and float((ref - torch.eye(64, device='cuda')).abs().max()) > 0.3
+    assert diag_err < 5e-5
+    assert float(cg.abs().max()) <= 1 + 5e-5
+    assert spot_err < 5e-5

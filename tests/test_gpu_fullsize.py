@@ -1,0 +1,176 @@
+"""The captured / fused loop iteration - the launch sequence bench.py times - against the torch-CPU
+oracle DIRECTLY, at every BASELINE.json configuration size (no graph-vs-eager self comparison).
+
+One ``T.train_iteration`` (hipGraph replay: fused RMSprop epilogues, critic tail kernels, chained input
+assembly, device Philox draws) is compared with ``oracle/cgan_oracle.py`` running the reference loop body
+(tf_utils.py:316-323: 5 x train_disc :186-223, then train_gen :226-258) on the SAME draws: the Philox z /
+alpha of the iteration are regenerated with the eager RNG entry points at the stream positions the graph
+uses (z_k then alpha_k per critic step, then the generator step's z; cgan.hip record_iteration).
+
+Stated fp32 tolerances:
+  * all nb_critic+1 losses: rtol 1e-4 (atol 1e-4 on |loss| < 1);
+  * weights after the iteration: 99.9 % of all weights within 2e-6 of the fp64 oracle AND of the fp32
+    oracle; and, tie-breaker, the GPU's 99.9 % error against the fp64 oracle is not
+    worse than 4x the fp32 oracle's own 99.9 % error against the fp64 oracle (+1e-7).  RMSprop divides by
+    sqrt(EMA(g^2)) + 1e-7, so single entries whose gradient is ~1e-7 may move by O(lr): the maximum is
+    bounded by 3 * steps * lr * sqrt(10) only as a sanity bound, the quantile is the check;
+  * full-size gradients (``apply=False``): max|err| <= 1e-4 * max|grad| per variable.
+
+The training path's oracle is "parity unpinned" by the reference (TensorFlow absent; see the oracle header).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import keras_list, make_problem, t64, tl
+from oracle import cgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EC_V = (6, 8, 5, 11, 5, 3, 5)
+# name: G, V, H, Z, B, p_aug   (SURVEY section 8 concrete configs)
+CONFIGS = {
+    'gtex_b32': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=32, p_aug=0),
+    'gtex_b512': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=512, p_aug=0),
+    'gtex_tail12': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=12, p_aug=0),      # 6860 mod 32
+    'ecoli_1076': dict(G=1076, V=EC_V, H=(128, 128), Z=10, B=32, p_aug=0.25),
+    'ecoli_4297': dict(G=4297, V=EC_V, H=(128, 128), Z=10, B=32, p_aug=0.25),
+    'wide_b32': dict(G=20000, V=(15, 3), H=(1024, 1024), Z=64, B=32, p_aug=0),
+}
+
+
+def _f32(a):
+    return np.asarray(a, np.float32)
+
+
+def _models(p):
+    from adversarial_gene_expression_amd import tf_utils as T
+    gen = T.Generator(p['G'], p['V'], p['n_num'], p['H'], p['Z'], weights=keras_list(p['gp']))
+    disc = T.Critic(p['G'], p['V'], p['n_num'], p['H'], 1, weights=keras_list(p['dp']))
+    return T, gen, disc
+
+
+def _graph_draws(T, seed, B, Z, nbc):
+    """The Philox draws a captured iteration makes when the module stream stands at (seed, offset 0):
+    per critic step z [B,Z] then alpha [B], then the generator step's z - drawn here through the eager
+    RNG entry points, which advance the stream position exactly as the graph does."""
+    T.set_seed(seed)
+    zs, als = [], []
+    for _ in range(nbc):
+        zs.append(T.random_normal((B, Z)).cpu().numpy())
+        als.append(T.random_uniform((B,)).cpu().numpy().reshape(B, 1))
+    zs.append(T.random_normal((B, Z)).cpu().numpy())
+    return zs, als, T._rng.offset
+
+
+def _aug_draws(np_seed, p_aug, norm_scale, B, G):
+    """The trace constants of tf_utils.py:202,209-210 then :240,247 in the order the product draws them."""
+    np.random.seed(np_seed)
+    mask_d = np.random.binomial(1, p_aug, B)
+    nf = np.random.normal(0, norm_scale, G)
+    nr = np.random.normal(0, norm_scale, (B, G))
+    mask_g = np.random.binomial(1, p_aug, B)
+    ng = np.random.normal(0, norm_scale, (B, G))
+    return dict(mask=mask_d, noise_fake=nf, noise_real=nr), dict(mask=mask_g, noise=ng)
+
+
+def _oracle_iteration(p, zs, als, dtype, aug_d=None, aug_g=None, lr=5e-4):
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=dtype)
+    tg, td = O.to_torch(p['gp'], dtype=dtype), O.to_torch(p['dp'], dtype=dtype)
+    go, do = O.RMSprop(lr), O.RMSprop(lr)
+    x, cc, nc = tt(p['x']), tl(p['cc']), tt(p['nc'])
+    kd = {} if aug_d is None else dict(aug_mask=tt(aug_d['mask']), aug_noise_fake=tt(aug_d['noise_fake']),
+                                       aug_noise_real=tt(aug_d['noise_real']))
+    kg = {} if aug_g is None else dict(aug_mask=tt(aug_g['mask']), aug_noise=tt(aug_g['noise']))
+    losses = []
+    for k in range(len(als)):
+        losses.append(float(O.train_disc(x, tt(zs[k]), cc, nc, tg, td, do, tt(als[k]), **kd)[0]))
+    losses.append(float(O.train_gen(tt(zs[-1]), cc, nc, tg, td, go, **kg)[0]))
+    flat = lambda tp: np.concatenate([t.detach().numpy().astype(np.float64).reshape(-1) for t in O.param_list(tp)])
+    return losses, flat(tg), flat(td)
+
+
+@pytest.mark.parametrize('name', sorted(CONFIGS))
+def test_captured_iteration_matches_oracle(gpu, name):
+    from adversarial_gene_expression_amd import _dev, _lib
+    from adversarial_gene_expression_amd._dev import ptr
+    c = CONFIGS[name]
+    nbc, lr, seed = 5, 5e-4, 4242
+    p = make_problem(G=c['G'], V=c['V'], H=c['H'], Z=c['Z'], B=c['B'], seed=17)
+    # the oracle sees exactly the fp32 inputs the GPU sees
+    p['x'] = _f32(p['x']).astype(np.float64)
+    T, gen, disc = _models(p)
+    torch.set_num_threads(16)
+    zs, als, end = _graph_draws(T, seed, c['B'], c['Z'], nbc)
+    aug_d = aug_g = None
+    if c['p_aug']:
+        aug_d, aug_g = _aug_draws(123, c['p_aug'], 0.5, c['B'], c['G'])
+        T._TRACE_CONSTS.clear()
+        np.random.seed(123)
+    T.set_seed(seed)
+    go, do = T.RMSprop(lr), T.RMSprop(lr)
+    xd, cd, nd = _dev.to_dev(_f32(p['x'])), _dev.to_dev(p['cc'], torch.int32), _dev.to_dev(_f32(p['nc']))
+    # what train() calls per batch; the losses of all steps are read back through the C-ABI launch below
+    lib = _lib.load()
+    pair = T._pair(gen, disc, c['B'], nbc + 1)
+    ad = ag = None
+    if c['p_aug']:
+        key = (id(gen), id(disc), c['B'], 0, c['B'])
+        ad = T._aug_constants('disc', key, c['p_aug'], 0.5, c['B'], c['G'])
+        ag = T._aug_constants('gen', key, c['p_aug'], 0.5, c['B'], c['G'])
+    g = pair.iteration_graph(gen, disc, go, do, c['B'], nbc, 10.0, seed, ad, ag)
+    losses = _dev.zeros((nbc + 1, 4))
+    _lib.check(lib.agx_cgan_iter_launch(g, _dev.stream(), ptr(xd), xd.stride(0), ptr(cd), ptr(nd), 0, ptr(losses)),
+               'agx_cgan_iter_launch')
+    assert int(lib.agx_cgan_iter_rng_draws(g)) == end     # the graph consumed the positions regenerated above
+    lg = losses.cpu().numpy()
+    got_losses = [float(lg[k, 2]) for k in range(nbc)] + [float(lg[nbc, 0])]
+    assert np.all(np.isfinite(lg))
+    got_g = np.concatenate([w.reshape(-1) for w in gen.get_weights()]).astype(np.float64)
+    got_d = np.concatenate([w.reshape(-1) for w in disc.get_weights()]).astype(np.float64)
+
+    l64, g64, d64 = _oracle_iteration(p, zs, als, torch.float64, aug_d, aug_g, lr)
+    l32, g32, d32 = _oracle_iteration(p, zs, als, torch.float32, aug_d, aug_g, lr)
+    np.testing.assert_allclose(got_losses, l64, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got_losses, l32, rtol=1e-4, atol=1e-4)
+    q = lambda e: float(np.quantile(e, 0.999))
+    for tag, got, w64, w32, steps in (('gen', got_g, g64, g32, 1), ('disc', got_d, d64, d32, nbc)):
+        moved = np.abs(w64 - np.concatenate([np.asarray(a, np.float64).reshape(-1) for a in
+                                             keras_list(p['gp' if tag == 'gen' else 'dp'], np.float64)]))
+        assert moved.max() > 0.5 * lr                      # the update really happened
+        e64, e32, o32 = np.abs(got - w64), np.abs(got - w32), np.abs(w32 - w64)
+        print('%s %s: q999 gpu-f64 %.3g gpu-f32 %.3g f32-f64 %.3g; max %.3g %.3g %.3g'
+              % (name, tag, q(e64), q(e32), q(o32), e64.max(), e32.max(), o32.max()))
+        assert q(e64) < 2e-6, (tag, q(e64))
+        assert q(e32) < 2e-6, (tag, q(e32))
+        assert q(e64) <= 4 * q(o32) + 1e-7, (tag, q(e64), q(o32))
+        assert e64.max() <= 3 * steps * lr * np.sqrt(10) + 1e-6
+
+
+@pytest.mark.parametrize('name', ['gtex_b32', 'gtex_b512', 'wide_b32', 'ecoli_4297'])
+def test_full_size_step_gradients(gpu, name):
+    """train_disc / train_gen gradients (apply=False) at the shipped shapes against fp64 autograd."""
+    c = CONFIGS[name]
+    p = make_problem(G=c['G'], V=c['V'], H=c['H'], Z=c['Z'], B=c['B'], seed=23)
+    p['x'] = _f32(p['x']).astype(np.float64)
+    p['z'] = _f32(p['z']).astype(np.float64)
+    p['alpha'] = _f32(p['alpha']).astype(np.float64)
+    T, gen, disc = _models(p)
+    torch.set_num_threads(16)
+
+    def check(got, want, what):
+        for i, (a, b) in enumerate(zip(got, want)):
+            b = np.asarray(b).reshape(a.shape)
+            err = float(np.max(np.abs(a - b))) if a.size else 0.0
+            assert err <= 1e-4 * float(np.max(np.abs(b))) + 1e-7, (what, i, err, float(np.max(np.abs(b))))
+
+    loss = T.train_disc(_f32(p['x']), _f32(p['z']), p['cc'], _f32(p['nc']), gen, disc, T.RMSprop(5e-4),
+                        alpha=_f32(p['alpha']), apply=False)
+    wl, _, want = O.disc_loss_and_grads(t64(p['x']), t64(p['z']), tl(p['cc']), t64(p['nc']), O.to_torch(p['gp']),
+                                        O.to_torch(p['dp']), t64(p['alpha']))
+    assert abs(float(loss) - float(wl)) <= 1e-4 * max(1.0, abs(float(wl)))
+    check(disc.get_gradients(), [g.numpy() for g in want], 'critic')
+    loss = T.train_gen(_f32(p['z']), p['cc'], _f32(p['nc']), gen, disc, T.RMSprop(5e-4), apply=False)
+    wl, want = O.gen_loss_and_grads(t64(p['z']), tl(p['cc']), t64(p['nc']), O.to_torch(p['gp']), O.to_torch(p['dp']))
+    assert abs(float(loss) - float(wl)) <= 1e-4 * max(1.0, abs(float(wl)))
+    check(gen.get_gradients(), [g.numpy() for g in want], 'generator')
