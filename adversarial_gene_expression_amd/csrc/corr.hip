@@ -5,11 +5,19 @@
 // itself is agx_corr_xtx in gemm.hip.
 #include "agx_common.h"
 
+#include <algorithm>
+#include <mutex>
+
 namespace {
 
 using agx::wave_sum;
 
-// blockDim 256 = 64 columns x 4 row phases; grid (ceil(G/64), row chunks)
+// Column statistics in two deterministic stages (no atomics: the result does not depend on the order
+// in which workgroups finish).  Stage 1: blockDim 256 = 64 columns x 4 row phases; grid (ceil(G/64),
+// row chunks); every chunk leaves its fp64 partial sums of (x - shift) and (x - shift)^2 per column in
+// ws[chunk][2][G], shift = the column's first row (sums about a value inside the data keep the
+// variance well conditioned when |mean| >> std: raw log-expression values).  Stage 2 adds the chunks
+// in index order.
 __global__ void __launch_bounds__(256) colstats_partial_kernel(const float *__restrict__ x, int ldx,
                                                                int N, int G, int rows_per_chunk,
                                                                double *__restrict__ ws) {
@@ -20,8 +28,9 @@ __global__ void __launch_bounds__(256) colstats_partial_kernel(const float *__re
   const int rend = min(N, rbeg + rows_per_chunk);
   double s = 0.0, q = 0.0;
   if (c < G) {
+    const double shift = (double)x[c];
     for (int r = rbeg + ty; r < rend; r += 4) {
-      const double v = (double)x[(size_t)r * ldx + c];
+      const double v = (double)x[(size_t)r * ldx + c] - shift;
       s += v;
       q += v * v;
     }
@@ -32,20 +41,27 @@ __global__ void __launch_bounds__(256) colstats_partial_kernel(const float *__re
   if (ty == 0 && c < G) {
     s = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
     q = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
-    atomicAdd(ws + c, s);
-    atomicAdd(ws + G + c, q);
+    double *w = ws + (size_t)blockIdx.y * 2 * G;
+    w[c] = s;
+    w[G + c] = q;
   }
 }
 
-__global__ void __launch_bounds__(256) colstats_finish_kernel(const double *__restrict__ ws, int N,
-                                                              int G, float *__restrict__ mean,
+__global__ void __launch_bounds__(256) colstats_finish_kernel(const double *__restrict__ ws, int chunks,
+                                                              const float *__restrict__ x, int N, int G,
+                                                              float *__restrict__ mean,
                                                               float *__restrict__ stdv) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= G) return;
-  const double m = ws[c] / (double)N;
-  double var = ws[G + c] / (double)N - m * m;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s += ws[(size_t)k * 2 * G + c];
+    q += ws[(size_t)k * 2 * G + G + c];
+  }
+  const double d = s / (double)N;          // mean - shift
+  double var = q / (double)N - d * d;
   if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
+  mean[c] = (float)((double)x[c] + d);
   stdv[c] = (float)sqrt(var);
 }
 
@@ -136,7 +152,9 @@ __global__ void __launch_bounds__(256) triu_write_kernel(const T *__restrict__ C
 }
 
 // ---- five sums for the 1-D Pearson ----------------------------------------
-__device__ __forceinline__ void block_add5(double (&s)[6], int nvals, double *__restrict__ sums) {
+// Deterministic: every block leaves its partial sums in part[block][6]; one finishing block adds the
+// blocks' partials in index order (fixed tree) to sums[] - no atomics, so gamma is bit-reproducible.
+__device__ __forceinline__ void block_add5(double (&s)[6], int nvals, double *__restrict__ part) {
   __shared__ double red[6][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -147,16 +165,36 @@ __device__ __forceinline__ void block_add5(double (&s)[6], int nvals, double *__
     }
   }
   __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    part[(size_t)blockIdx.x * 6 + k] = k < nvals ? red[k][0] + red[k][1] + red[k][2] + red[k][3] : 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) sums_finish_kernel(const double *__restrict__ part, int nblocks,
+                                                          int nvals, double *__restrict__ sums) {
+  __shared__ double red[6][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += part[(size_t)b * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double v = wave_sum(s[k]);
+    if (lane == 0) red[k][wave] = v;
+  }
+  __syncthreads();
   if (threadIdx.x < nvals) {
     const int k = threadIdx.x;
-    atomicAdd(sums + k, red[k][0] + red[k][1] + red[k][2] + red[k][3]);
+    sums[k] += red[k][0] + red[k][1] + red[k][2] + red[k][3];
   }
 }
 
 __global__ void __launch_bounds__(256) pearson_sums_kernel(const float *__restrict__ a,
                                                            const float *__restrict__ b, long long n,
                                                            int one_minus,
-                                                           double *__restrict__ sums) {
+                                                           double *__restrict__ part) {
   double s[6] = {0, 0, 0, 0, 0, 0};
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -168,12 +206,12 @@ __global__ void __launch_bounds__(256) pearson_sums_kernel(const float *__restri
     const double da = fa, db = fb;
     s[0] += da; s[1] += db; s[2] += da * da; s[3] += db * db; s[4] += da * db;
   }
-  block_add5(s, 5, sums);
+  block_add5(s, 5, part);
 }
 
 __global__ void __launch_bounds__(256) gamma_sums_kernel(const float *__restrict__ C1, int ld1,
                                                          const float *__restrict__ C2, int ld2,
-                                                         int G, double *__restrict__ sums) {
+                                                         int G, double *__restrict__ part) {
   double s[6] = {0, 0, 0, 0, 0, 0};
   for (int i = blockIdx.x; i < G; i += gridDim.x) {
     const float *r1 = C1 + (size_t)i * ld1;
@@ -188,22 +226,23 @@ __global__ void __launch_bounds__(256) gamma_sums_kernel(const float *__restrict
       }
     }
   }
-  block_add5(s, 6, sums);
+  block_add5(s, 6, part);
 }
 
 // same sums over a range of the upper-triangular 128x128 tile list of agx_corr_xtx (the tiles one
 // rank owns when the G x G matrix is dealt across GPUs): one block per tile
 __global__ void __launch_bounds__(256) gamma_sums_tiles_kernel(const float *__restrict__ C1, int ld1,
                                                                const float *__restrict__ C2, int ld2,
-                                                               int G, long long tile_begin, int tiles_1d,
-                                                               double *__restrict__ sums) {
-  int ti, tj;
-  agx::tri_decode(tile_begin + blockIdx.x, tiles_1d, ti, tj);
-  const int i0 = ti * 128, j0 = tj * 128;
+                                                               int G, long long tile_begin, long long tile_end,
+                                                               int tiles_1d, double *__restrict__ part) {
   const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
   double s[6] = {0, 0, 0, 0, 0, 0};
-  const int j = j0 + tx;
-  if (j < G) {
+  for (long long t = tile_begin + blockIdx.x; t < tile_end; t += gridDim.x) {
+    int ti, tj;
+    agx::tri_decode(t, tiles_1d, ti, tj);
+    const int i0 = ti * 128, j0 = tj * 128;
+    const int j = j0 + tx;
+    if (j >= G) continue;
     for (int r = ty; r < 128; r += 2) {
       const int i = i0 + r;
       if (i >= G || j <= i) continue;
@@ -216,28 +255,95 @@ __global__ void __launch_bounds__(256) gamma_sums_tiles_kernel(const float *__re
       }
     }
   }
-  block_add5(s, 6, sums);
+  block_add5(s, 6, part);
+}
+
+// Scratch of the allocation-free entry point (agx_colstats_noalloc): one copy per GPU, held until the
+// process ends.  In host code this name is only a stand-in for the symbol: the device address comes
+// from hipGetSymbolAddress, once per device (scratch_for_current_device).
+static __device__ __align__(256) double scratch[AGX_COLSTATS_NOALLOC_DOUBLES];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double *g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_for_current_device(double **out) {
+  int dev = -1;
+  AGX_HIP(hipGetDevice(&dev));
+  AGX_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "agx_colstats_noalloc: device index %d unsupported", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    double *p = nullptr;
+    AGX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+    AGX_CHECK_ARG(p != nullptr, "agx_colstats_noalloc: hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return AGX_OK;
+}
+
+// row chunks of the first stage: enough workgroups to fill the part, at least 64 rows each
+int colstats_chunks(int N, int G) {
+  const int gx = agx::cdiv(G, 64);
+  int chunks = std::max(1, std::min(agx::cdiv(N, 64), agx::cdiv(4 * agx::num_cus(), gx)));
+  const int rpc = agx::cdiv(N, chunks);
+  return agx::cdiv(N, rpc);
+}
+
+int colstats_run(hipStream_t st, const float *x, int ldx, int N, int G, float *mean, float *std, double *ws,
+                 int chunks) {
+  const int gx = agx::cdiv(G, 64);
+  const int rpc = agx::cdiv(N, chunks);
+  chunks = agx::cdiv(N, rpc);
+  hipLaunchKernelGGL(colstats_partial_kernel, dim3(gx, chunks), dim3(256), 0, st, x, ldx, N, G, rpc, ws);
+  AGX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colstats_finish_kernel, dim3(agx::cdiv(G, 256)), dim3(256), 0, st, ws, chunks, x, N, G,
+                     mean, std);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int sums_finish(hipStream_t st, const double *part, int nblocks, int nvals, double *sums) {
+  hipLaunchKernelGGL(sums_finish_kernel, dim3(1), dim3(256), 0, st, part, nblocks, nvals, sums);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
 }
 
 }  // namespace
 
+extern "C" int64_t agx_colstats_ws_doubles(int32_t N, int32_t G) {
+  if (N <= 0 || G <= 0) return 0;
+  return (int64_t)2 * G * colstats_chunks(N, G);
+}
+
 extern "C" int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
-                            float *mean, float *std, double *ws) {
+                            float *mean, float *std, double *ws, int64_t ws_doubles) {
   AGX_CHECK_ARG(x && mean && std && ws, "agx_colstats: null argument");
   AGX_CHECK_ARG(N > 0 && G > 0 && ldx >= G, "agx_colstats: bad shape N=%d G=%d ldx=%d", N, G, ldx);
-  hipStream_t st = agx::as_stream(stream);
-  AGX_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)G, st));
-  const int gx = agx::cdiv(G, 64);
-  int chunks = std::max(1, std::min(agx::cdiv(N, 64), agx::cdiv(4 * agx::num_cus(), gx)));
-  const int rpc = agx::cdiv(N, chunks);
-  chunks = agx::cdiv(N, rpc);
-  hipLaunchKernelGGL(colstats_partial_kernel, dim3(gx, chunks), dim3(256), 0, st, x, ldx, N, G, rpc,
-                     ws);
-  AGX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colstats_finish_kernel, dim3(agx::cdiv(G, 256)), dim3(256), 0, st, ws, N, G,
-                     mean, std);
-  AGX_LAUNCH_CHECK();
-  return AGX_OK;
+  const int chunks = colstats_chunks(N, G);
+  if (ws_doubles < (int64_t)2 * G * chunks) {
+    agx::set_error("agx_colstats: workspace of %lld doubles < agx_colstats_ws_doubles(%d, %d) = %lld",
+                   (long long)ws_doubles, N, G, (long long)2 * G * chunks);
+    return AGX_E_WORKSPACE;
+  }
+  return colstats_run(agx::as_stream(stream), x, ldx, N, G, mean, std, ws, chunks);
+}
+
+extern "C" int agx_colstats_noalloc(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
+                                    float *mean, float *std) {
+  AGX_CHECK_ARG(x && mean && std, "agx_colstats_noalloc: null argument");
+  AGX_CHECK_ARG(N > 0 && G > 0 && ldx >= G, "agx_colstats_noalloc: bad shape N=%d G=%d ldx=%d", N, G, ldx);
+  const int chunks = colstats_chunks(N, G);
+  if (G > AGX_COLSTATS_NOALLOC_MAX_G || (int64_t)2 * G * chunks > AGX_COLSTATS_NOALLOC_DOUBLES) {
+    agx::set_error("agx_colstats_noalloc: G=%d exceeds the static scratch (max G = %d, %d doubles per GPU); "
+                   "use agx_colstats with a caller workspace", G, AGX_COLSTATS_NOALLOC_MAX_G,
+                   AGX_COLSTATS_NOALLOC_DOUBLES);
+    return AGX_E_INVALID;
+  }
+  double *ws = nullptr;
+  AGX_TRY(scratch_for_current_device(&ws));
+  // every partial slot the second stage reads is written by the first: nothing has to start at zero
+  return colstats_run(agx::as_stream(stream), x, ldx, N, G, mean, std, ws, chunks);
 }
 
 extern "C" int agx_standardize(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
@@ -288,38 +394,42 @@ extern "C" int agx_triu_pack_f64(void *stream, const double *C, int32_t ldc, int
   return triu_pack_impl<double>(stream, C, ldc, G, out, row_counts, row_offsets, n_out_dev);
 }
 
+extern "C" int64_t agx_sums_ws_doubles(void) { return 6 * 2048; }
+
 extern "C" int agx_pearson_sums(void *stream, const float *a, const float *b, int64_t n,
-                                int32_t one_minus, double *sums) {
-  AGX_CHECK_ARG(a && b && sums && n >= 0, "agx_pearson_sums: bad argument");
+                                int32_t one_minus, double *sums, double *ws) {
+  AGX_CHECK_ARG(a && b && sums && ws && n >= 0, "agx_pearson_sums: bad argument");
   if (n == 0) return AGX_OK;
   int blocks = (int)std::min<int64_t>(agx::cdiv64(n, 256 * 8), 2048);
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(pearson_sums_kernel, dim3(blocks), dim3(256), 0, agx::as_stream(stream), a, b,
-                     (long long)n, one_minus, sums);
+  hipStream_t st = agx::as_stream(stream);
+  hipLaunchKernelGGL(pearson_sums_kernel, dim3(blocks), dim3(256), 0, st, a, b, (long long)n, one_minus, ws);
   AGX_LAUNCH_CHECK();
-  return AGX_OK;
+  return sums_finish(st, ws, blocks, 5, sums);
 }
 
 extern "C" int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const float *C2,
-                              int32_t ld2, int32_t G, double *sums) {
-  AGX_CHECK_ARG(C1 && C2 && sums && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums: bad argument");
-  hipLaunchKernelGGL(gamma_sums_kernel, dim3(std::min(G, 2048)), dim3(256), 0,
-                     agx::as_stream(stream), C1, ld1, C2, ld2, G, sums);
+                              int32_t ld2, int32_t G, double *sums, double *ws) {
+  AGX_CHECK_ARG(C1 && C2 && sums && ws && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums: bad argument");
+  hipStream_t st = agx::as_stream(stream);
+  const int blocks = std::min(G, 2048);
+  hipLaunchKernelGGL(gamma_sums_kernel, dim3(blocks), dim3(256), 0, st, C1, ld1, C2, ld2, G, ws);
   AGX_LAUNCH_CHECK();
-  return AGX_OK;
+  return sums_finish(st, ws, blocks, 6, sums);
 }
 
 extern "C" int agx_gamma_sums_tiles(void *stream, const float *C1, int32_t ld1, const float *C2,
                                     int32_t ld2, int32_t G, int64_t tile_begin, int64_t tile_end,
-                                    double *sums) {
-  AGX_CHECK_ARG(C1 && C2 && sums && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums_tiles: bad argument");
+                                    double *sums, double *ws) {
+  AGX_CHECK_ARG(C1 && C2 && sums && ws && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums_tiles: bad argument");
   const int64_t total = agx_corr_num_tiles(G);
   if (tile_end < 0 || tile_end > total) tile_end = total;
   AGX_CHECK_ARG(tile_begin >= 0 && tile_begin <= tile_end, "agx_gamma_sums_tiles: bad tile range");
   if (tile_begin == tile_end) return AGX_OK;
-  hipLaunchKernelGGL(gamma_sums_tiles_kernel, dim3((unsigned)(tile_end - tile_begin)), dim3(256), 0,
-                     agx::as_stream(stream), C1, ld1, C2, ld2, G, (long long)tile_begin,
-                     agx::cdiv(G, 128), sums);
+  hipStream_t st = agx::as_stream(stream);
+  const int blocks = (int)std::min<int64_t>(tile_end - tile_begin, 2048);
+  hipLaunchKernelGGL(gamma_sums_tiles_kernel, dim3(blocks), dim3(256), 0, st, C1, ld1, C2, ld2, G,
+                     (long long)tile_begin, (long long)tile_end, agx::cdiv(G, 128), ws);
   AGX_LAUNCH_CHECK();
-  return AGX_OK;
+  return sums_finish(st, ws, blocks, 6, sums);
 }

@@ -8,13 +8,27 @@ alpha of the iteration are regenerated with the eager RNG entry points at the st
 uses (z_k then alpha_k per critic step, then the generator step's z; cgan.hip record_iteration).
 
 Stated fp32 tolerances:
-  * all nb_critic+1 losses: rtol 1e-4 (atol 1e-4 on |loss| < 1);
+  * all nb_critic+1 losses: within 1e-4 * max(1, largest |loss| of the iteration) of the fp64 oracle (a loss
+    is a difference of critic outputs of that magnitude: the fp32 ORACLE's generator loss at 512 rows is
+    already 3.7e-4 relative away from the fp64 one), and not worse than 4x the fp32 oracle's own error + 1e-5;
   * weights after the iteration: 99.9 % of all weights within 2e-6 of the fp64 oracle AND of the fp32
     oracle; and, tie-breaker, the GPU's 99.9 % error against the fp64 oracle is not
     worse than 4x the fp32 oracle's own 99.9 % error against the fp64 oracle (+1e-7).  RMSprop divides by
     sqrt(EMA(g^2)) + 1e-7, so single entries whose gradient is ~1e-7 may move by O(lr): the maximum is
     bounded by 3 * steps * lr * sqrt(10) only as a sanity bound, the quantile is the check;
   * full-size gradients (``apply=False``): max|err| <= 1e-4 * max|grad| per variable.
+
+512 rows: the objective is DISCONTINUOUS in the critic's ReLU masks (the penalty's slope is a gradient), and a
+pre-activation within fp32 rounding (~1e-6) of zero flips one: expected 3*512 rows x 512 units x 2e-6 x
+density 0.28 = 0.4 flips per critic step (0.03 at 32 rows).  One flip moves one column of W_1 by O(lr) and
+the difference then grows ~30x per step (every weight of that unit moves coherently).  Measured
+(tools/diag_graph_vs_eager.py, profiles/r02_flip_diag.txt): graph == eager step functions bit for bit up to 3
+critic steps and both track the fp64 oracle like the fp32 oracle does (99.9 % within 2.6e-8); in the 4th
+step one mask of unit 49 differs between graph and eager (17049 of the 17050 differing W_1 entries are
+column 49), the fp32 ORACLE has its own flip in that step (bias-gradient error 1e-4 instead of 1e-8).
+Hence two cases at 512 rows: `gtex_b512` = 2 critic steps + generator step at the tight bounds above;
+`gtex_b512_5steps` = the bench iteration with flip-aware bounds: losses within 1e-3 * scale, median weight
+error < 1e-5, 99 % < 1e-4 (a wrong kernel moves EVERY weight by O(lr) = 5e-4 per step).
 
 The training path's oracle is "parity unpinned" by the reference (TensorFlow absent; see the oracle header).
 """
@@ -31,7 +45,8 @@ EC_V = (6, 8, 5, 11, 5, 3, 5)
 # name: G, V, H, Z, B, p_aug   (SURVEY section 8 concrete configs)
 CONFIGS = {
     'gtex_b32': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=32, p_aug=0),
-    'gtex_b512': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=512, p_aug=0),
+    'gtex_b512': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=512, p_aug=0, nbc=2),
+    'gtex_b512_5steps': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=512, p_aug=0, loose=True),
     'gtex_tail12': dict(G=18154, V=(15, 3), H=(256, 256), Z=64, B=12, p_aug=0),      # 6860 mod 32
     'ecoli_1076': dict(G=1076, V=EC_V, H=(128, 128), Z=10, B=32, p_aug=0.25),
     'ecoli_4297': dict(G=4297, V=EC_V, H=(128, 128), Z=10, B=32, p_aug=0.25),
@@ -95,7 +110,7 @@ def test_captured_iteration_matches_oracle(gpu, name):
     from adversarial_gene_expression_amd import _dev, _lib
     from adversarial_gene_expression_amd._dev import ptr
     c = CONFIGS[name]
-    nbc, lr, seed = 5, 5e-4, 4242
+    nbc, lr, seed, loose = c.get('nbc', 5), 5e-4, 4242, c.get('loose', False)
     p = make_problem(G=c['G'], V=c['V'], H=c['H'], Z=c['Z'], B=c['B'], seed=17)
     # the oracle sees exactly the fp32 inputs the GPU sees
     p['x'] = _f32(p['x']).astype(np.float64)
@@ -131,8 +146,13 @@ def test_captured_iteration_matches_oracle(gpu, name):
 
     l64, g64, d64 = _oracle_iteration(p, zs, als, torch.float64, aug_d, aug_g, lr)
     l32, g32, d32 = _oracle_iteration(p, zs, als, torch.float32, aug_d, aug_g, lr)
-    np.testing.assert_allclose(got_losses, l64, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(got_losses, l32, rtol=1e-4, atol=1e-4)
+    scale = max(1.0, float(np.max(np.abs(l64))))
+    el = np.abs(np.array(got_losses) - np.array(l64))
+    eo = np.abs(np.array(l32) - np.array(l64))
+    print('%s losses: gpu %s | f64 %s | max err gpu-f64 %.3g, f32-f64 %.3g' % (name, got_losses, l64, el.max(), eo.max()))
+    fails = []
+    if not el.max() <= (1e-3 if loose else 1e-4) * scale: fails.append(('loss', el.max()))
+    if not loose and not el.max() <= 4 * eo.max() + 1e-5 * scale: fails.append(('loss-tie', el.max(), eo.max()))
     q = lambda e: float(np.quantile(e, 0.999))
     for tag, got, w64, w32, steps in (('gen', got_g, g64, g32, 1), ('disc', got_d, d64, d32, nbc)):
         moved = np.abs(w64 - np.concatenate([np.asarray(a, np.float64).reshape(-1) for a in
@@ -141,10 +161,16 @@ def test_captured_iteration_matches_oracle(gpu, name):
         e64, e32, o32 = np.abs(got - w64), np.abs(got - w32), np.abs(w32 - w64)
         print('%s %s: q999 gpu-f64 %.3g gpu-f32 %.3g f32-f64 %.3g; max %.3g %.3g %.3g'
               % (name, tag, q(e64), q(e32), q(o32), e64.max(), e32.max(), o32.max()))
-        assert q(e64) < 2e-6, (tag, q(e64))
-        assert q(e32) < 2e-6, (tag, q(e32))
-        assert q(e64) <= 4 * q(o32) + 1e-7, (tag, q(e64), q(o32))
-        assert e64.max() <= 3 * steps * lr * np.sqrt(10) + 1e-6
+        print('   fraction > 2e-6: gpu-f64 %.3g gpu-f32 %.3g f32-f64 %.3g' % ((e64 > 2e-6).mean(), (e32 > 2e-6).mean(), (o32 > 2e-6).mean()))
+        if loose:
+            if not np.median(e64) < 1e-5: fails.append((tag, 'median', float(np.median(e64))))
+            if not np.quantile(e64, 0.99) < 1e-4: fails.append((tag, 'q99', float(np.quantile(e64, 0.99))))
+            continue
+        if not q(e64) < 2e-6: fails.append((tag, q(e64)))
+        if not q(e32) < 2e-6: fails.append((tag, q(e32)))
+        if not q(e64) <= 4 * q(o32) + 1e-7: fails.append((tag, q(e64), q(o32)))
+        if not e64.max() <= 3 * steps * lr * np.sqrt(10) + 1e-6: fails.append((tag, 'max', e64.max()))
+    assert not fails, fails
 
 
 @pytest.mark.parametrize('name', ['gtex_b32', 'gtex_b512', 'wide_b32', 'ecoli_4297'])
