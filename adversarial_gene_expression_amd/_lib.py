@@ -177,15 +177,17 @@ SIGNATURES = {
     'agx_stack_rows': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32,
                                  _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32]),
     'agx_small_grads': (C.c_int, [_vp, C.POINTER(SmallGrads)]),
-    'agx_colstats': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'agx_colstats_ws_doubles': (_i64, [_i32, _i32]),
+    'agx_colstats': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64]),
     'agx_standardize': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
     'agx_corr_xtx': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i64, _i64]),
     'agx_corr_num_tiles': (_i64, [_i32]),
     'agx_triu_pack': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'agx_triu_pack_f64': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
-    'agx_pearson_sums': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
-    'agx_gamma_sums': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
-    'agx_gamma_sums_tiles': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i64, _i64, _vp]),
+    'agx_sums_ws_doubles': (_i64, []),
+    'agx_pearson_sums': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    'agx_gamma_sums': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    'agx_gamma_sums_tiles': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
     'agx_cgan_create': (C.c_int, [C.POINTER(CganConfig), C.POINTER(_vp)]),
     'agx_cgan_destroy': (C.c_int, [_vp]),
     'agx_cgan_workspace_bytes': (_i64, [_vp]),

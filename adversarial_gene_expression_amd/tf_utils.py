@@ -308,7 +308,9 @@ def wasserstein_loss(y_true, y_pred):
     lib = _lib.load()
     a, b = _flat_dev(y_true), _flat_dev(y_pred)
     sums = _dev.zeros(8, dtype=torch.float64)
-    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), a.numel(), 0, ptr(sums)), 'agx_pearson_sums')
+    ws = _dev.empty(int(lib.agx_sums_ws_doubles()), dtype=torch.float64)
+    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), a.numel(), 0, ptr(sums), ptr(ws)),
+               'agx_pearson_sums')
     return np.float32(sums[4].item() / a.numel())
 
 

@@ -42,8 +42,9 @@ def _colstats_dev(xd, ld, n, g):
     lib = _lib.load()
     mean = _dev.empty(g)
     std = _dev.empty(g)
-    ws = _dev.empty(2 * g, dtype=torch.float64)
-    _lib.check(lib.agx_colstats(_dev.stream(), ptr(xd), ld, n, g, ptr(mean), ptr(std), ptr(ws)), 'agx_colstats')
+    nws = int(lib.agx_colstats_ws_doubles(n, g))
+    ws = _dev.empty(nws, dtype=torch.float64)
+    _lib.check(lib.agx_colstats(_dev.stream(), ptr(xd), ld, n, g, ptr(mean), ptr(std), ptr(ws), nws), 'agx_colstats')
     return mean, std
 
 
@@ -101,8 +102,14 @@ def _pearson_1d_dev(a, b, one_minus=False):
     lib = _lib.load()
     n = a.numel()
     sums = _dev.zeros(8, dtype=torch.float64)
-    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums)), 'agx_pearson_sums')
+    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums), ptr(_sums_ws())),
+               'agx_pearson_sums')
     return _r_from_sums(sums.cpu().numpy(), n)
+
+
+def _sums_ws():
+    """Scratch for the workgroups' partial sums of the deterministic five-sum reductions."""
+    return _dev.empty(int(_lib.load().agx_sums_ws_doubles()), dtype=torch.float64)
 
 
 def _r_from_sums(s, n):
@@ -223,8 +230,8 @@ def gamma_coef(x, y):
     if world > 1:
         cx, ldx, g = _corr_self_dev(x, (tb, te))
         cy, ldy, _ = _corr_self_dev(y, (tb, te))
-        _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, tb, te, ptr(sums)),
-                   'agx_gamma_sums_tiles')
+        _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, tb, te, ptr(sums),
+                                            ptr(_sums_ws())), 'agx_gamma_sums_tiles')
         _dev.allreduce_sum(sums)
         s = sums.cpu().numpy()
         if s[5] == 0:
@@ -233,7 +240,8 @@ def gamma_coef(x, y):
         sums.zero_()        # NaNs present: every rank takes the packed (replicated) path below
     cx, ldx, g = _corr_self_dev(x)
     cy, ldy, g2 = _corr_self_dev(y)
-    _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, ptr(sums)), 'agx_gamma_sums')
+    _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, ptr(sums), ptr(_sums_ws())),
+               'agx_gamma_sums')
     s = sums.cpu().numpy()
     if s[5] == 0:
         r = _r_from_sums(s, g * (g - 1) // 2)
@@ -274,15 +282,15 @@ class GammaScorer:
         if self.world > 1:
             cy, ldy, _ = _corr_self_dev(x_gen, (self.tb, self.te))
             _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(self.cx), self.ldx, ptr(cy), ldy, g, self.tb, self.te,
-                                                ptr(sums)), 'agx_gamma_sums_tiles')
+                                                ptr(sums), ptr(_sums_ws())), 'agx_gamma_sums_tiles')
             _dev.allreduce_sum(sums)
             s = sums.cpu().numpy()
             if s[5] != 0:
                 return gamma_coef(self._x, x_gen)
         else:
             cy, ldy, _ = _corr_self_dev(x_gen)
-            _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(self.cx), self.ldx, ptr(cy), ldy, g, ptr(sums)),
-                       'agx_gamma_sums')
+            _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(self.cx), self.ldx, ptr(cy), ldy, g, ptr(sums),
+                                          ptr(_sums_ws())), 'agx_gamma_sums')
             s = sums.cpu().numpy()
             if s[5] != 0:
                 lx = _triu_pack_dev(self.cx, self.ldx, g)

@@ -240,7 +240,8 @@ def run_corr(world, rank, n_big, G=18154, n_eval=2287):
         x[r0:r1] = torch.randn(r1 - r0, ld, device='cuda', generator=g)
     st = _dev.stream()
     mean, std = _dev.empty(G), _dev.empty(G)
-    ws = _dev.empty(2 * G, dtype=torch.float64)
+    nws = int(lib.agx_colstats_ws_doubles(n_big, G))
+    ws = _dev.empty(nws, dtype=torch.float64)
     xs = torch.empty_like(x)
     c = _dev.empty((G, ld))
     total = int(lib.agx_corr_num_tiles(G))
@@ -250,7 +251,7 @@ def run_corr(world, rank, n_big, G=18154, n_eval=2287):
 
     def once():
         ev[0].record()
-        _lib.check(lib.agx_colstats(st, x.data_ptr(), ld, n_big, G, mean.data_ptr(), std.data_ptr(), ws.data_ptr()))
+        _lib.check(lib.agx_colstats(st, x.data_ptr(), ld, n_big, G, mean.data_ptr(), std.data_ptr(), ws.data_ptr(), nws))
         _lib.check(lib.agx_standardize(st, x.data_ptr(), ld, n_big, G, mean.data_ptr(), std.data_ptr(), xs.data_ptr(), ld))
         ev[1].record()
         _lib.check(lib.agx_corr_xtx(st, xs.data_ptr(), ld, n_big, G, 1.0 / n_big, c.data_ptr(), ld, tb, te))

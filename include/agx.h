@@ -253,10 +253,13 @@ int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_dev, int32_t
                   const agx_rng_seg_t *segs_host);
 
 /* ---- correlation path: utils.py:260-268, 808-873 ------------------------ */
-/* per-column mean and population std (ddof=0) of x[N,G]; sums in fp64.
- * ws: 2*G doubles of scratch.  (utils.py:816-818, 264-267) */
+/* per-column mean and population std (ddof=0) of x[N,G]  (utils.py:816-818, 264-267).  Two
+ * deterministic stages (per-row-chunk fp64 partial sums about the column's first value, then a
+ * fixed-order add: no atomics, bit-reproducible, well conditioned for |mean| >> std).
+ * ws: agx_colstats_ws_doubles(N, G) doubles of scratch; nothing in it has to be initialised. */
+int64_t agx_colstats_ws_doubles(int32_t N, int32_t G);
 int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G, float *mean,
-                 float *std, double *ws);
+                 float *std, double *ws, int64_t ws_doubles);
 /* out = (x - mean) / std  (utils.py:268, 819) */
 int agx_standardize(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
                     const float *mean, const float *std, float *out, int32_t ldo);
@@ -274,19 +277,22 @@ int agx_triu_pack(void *stream, const float *C, int32_t ldc, int32_t G, float *o
 int agx_triu_pack_f64(void *stream, const double *C, int32_t ldc, int32_t G, double *out,
                       int64_t *row_counts, int64_t *row_offsets, int64_t *n_out_dev);
 /* sums[0..4] (fp64) += sum a, sum b, sum a^2, sum b^2, sum ab over two fp32 vectors
- * transformed as (one_minus ? 1-v : v); the 1-D Pearson of utils.py:872 follows on host. */
+ * transformed as (one_minus ? 1-v : v); the 1-D Pearson of utils.py:872 follows on host.
+ * ws (here and in the two calls below): agx_sums_ws_doubles() doubles of scratch for the
+ * workgroups' partial sums, added in index order by a finishing launch (deterministic). */
+int64_t agx_sums_ws_doubles(void);
 int agx_pearson_sums(void *stream, const float *a, const float *b, int64_t n, int32_t one_minus,
-                     double *sums);
+                     double *sums, double *ws);
 /* Same five sums taken directly over the strict upper triangles of two G x G matrices
  * (1 - c), plus sums[5] = number of NaN entries met (then the caller must use the
  * packed path to reproduce the reference's NaN-dropping).  utils.py:863-873 fused. */
 int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const float *C2, int32_t ld2,
-                   int32_t G, double *sums);
+                   int32_t G, double *sums, double *ws);
 /* The same six sums over tiles [tile_begin, tile_end) of agx_corr_xtx's upper-triangular 128x128
  * tile list only (the share of one rank when the matrix is dealt across GPUs; the ranks' sums
  * add up to agx_gamma_sums' and are combined with one all-reduce of 6 doubles). */
 int agx_gamma_sums_tiles(void *stream, const float *C1, int32_t ld1, const float *C2, int32_t ld2,
-                         int32_t G, int64_t tile_begin, int64_t tile_end, double *sums);
+                         int32_t G, int64_t tile_begin, int64_t tile_end, double *sums, double *ws);
 
 /* ---- whole train step: tf_utils.py:186-258 ------------------------------ */
 typedef struct agx_mlp_desc {

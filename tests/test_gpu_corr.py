@@ -137,14 +137,15 @@ def test_gamma_sums_over_tile_ranges_add_up(gpu):
     cx, ldx, g = U._corr_self_dev(x)
     cy, ldy, _ = U._corr_self_dev(y)
     ref = _dev.zeros(8, dtype=torch.float64)
-    _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, ptr(ref)))
+    _lib.check(lib.agx_gamma_sums(_dev.stream(), ptr(cx), ldx, ptr(cy), ldy, g, ptr(ref), ptr(U._sums_ws())))
     nt = int(lib.agx_corr_num_tiles(g))
     acc = _dev.zeros(8, dtype=torch.float64)
     for r in range(3):
         lo, hi = r * nt // 3, (r + 1) * nt // 3
         px, _, _ = U._corr_self_dev(x, (lo, hi))     # only this rank's tiles are defined
         py, _, _ = U._corr_self_dev(y, (lo, hi))
-        _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(px), ldx, ptr(py), ldy, g, lo, hi, ptr(acc)))
+        _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(px), ldx, ptr(py), ldy, g, lo, hi, ptr(acc),
+                                            ptr(U._sums_ws())))
     a, b = acc.cpu().numpy(), ref.cpu().numpy()
     assert a[5] == 0 and b[5] == 0
     np.testing.assert_allclose(a[:5], b[:5], rtol=1e-12)
@@ -203,10 +204,11 @@ def test_corr_100k_samples_properties(gpu):
         x[r0:r1] = (f @ load + 2.0 * torch.randn(r1 - r0, ld, device='cuda', generator=gen)) * scale + shift
     st = _dev.stream()
     mean, std = _dev.empty(G), _dev.empty(G)
-    ws = _dev.empty(2 * G, dtype=torch.float64)
+    nws = int(lib.agx_colstats_ws_doubles(N, G))
+    ws = _dev.empty(nws, dtype=torch.float64)
     xs = torch.empty_like(x)
     c = _dev.empty((G, ld))
-    _lib.check(lib.agx_colstats(st, ptr(x), ld, N, G, ptr(mean), ptr(std), ptr(ws)))
+    _lib.check(lib.agx_colstats(st, ptr(x), ld, N, G, ptr(mean), ptr(std), ptr(ws), nws))
     _lib.check(lib.agx_standardize(st, ptr(x), ld, N, G, ptr(mean), ptr(std), ptr(xs), ld))
     _lib.check(lib.agx_corr_xtx(st, ptr(xs), ld, N, G, 1.0 / N, ptr(c), ld, 0, -1))
     torch.cuda.synchronize()
