@@ -179,6 +179,7 @@ SIGNATURES = {
     'agx_small_grads': (C.c_int, [_vp, C.POINTER(SmallGrads)]),
     'agx_colstats_ws_doubles': (_i64, [_i32, _i32]),
     'agx_colstats': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64]),
+    'agx_colstats_noalloc': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'agx_standardize': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
     'agx_corr_xtx': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _i64, _i64]),
     'agx_corr_num_tiles': (_i64, [_i32]),

@@ -6,6 +6,7 @@
 #include "agx_common.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -257,6 +258,30 @@ __global__ void __launch_bounds__(256) gamma_sums_tiles_kernel(const float *__re
   block_add5(s, 6, part);
 }
 
+// Scratch of the allocation-free entry point (agx_colstats_noalloc): one copy per GPU, held until the
+// process ends.  In host code this name is only a stand-in for the symbol: the device address comes
+// from hipGetSymbolAddress, once per device (scratch_for_current_device).
+static __device__ __align__(256) double scratch[AGX_COLSTATS_NOALLOC_DOUBLES];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double *g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_for_current_device(double **out) {
+  int dev = -1;
+  AGX_HIP(hipGetDevice(&dev));
+  AGX_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "agx_colstats_noalloc: device index %d unsupported", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    double *p = nullptr;
+    AGX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+    AGX_CHECK_ARG(p != nullptr, "agx_colstats_noalloc: hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return AGX_OK;
+}
+
 // row chunks of the first stage: enough workgroups to fill the part, at least 64 rows each
 int colstats_chunks(int N, int G) {
   const int gx = agx::cdiv(G, 64);
@@ -301,6 +326,23 @@ extern "C" int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N
                    (long long)ws_doubles, N, G, (long long)2 * G * chunks);
     return AGX_E_WORKSPACE;
   }
+  return colstats_run(agx::as_stream(stream), x, ldx, N, G, mean, std, ws, chunks);
+}
+
+extern "C" int agx_colstats_noalloc(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
+                                    float *mean, float *std) {
+  AGX_CHECK_ARG(x && mean && std, "agx_colstats_noalloc: null argument");
+  AGX_CHECK_ARG(N > 0 && G > 0 && ldx >= G, "agx_colstats_noalloc: bad shape N=%d G=%d ldx=%d", N, G, ldx);
+  const int chunks = colstats_chunks(N, G);
+  if (G > AGX_COLSTATS_NOALLOC_MAX_G || (int64_t)2 * G * chunks > AGX_COLSTATS_NOALLOC_DOUBLES) {
+    agx::set_error("agx_colstats_noalloc: G=%d exceeds the static scratch (max G = %d, %d doubles per GPU); "
+                   "use agx_colstats with a caller workspace", G, AGX_COLSTATS_NOALLOC_MAX_G,
+                   AGX_COLSTATS_NOALLOC_DOUBLES);
+    return AGX_E_INVALID;
+  }
+  double *ws = nullptr;
+  AGX_TRY(scratch_for_current_device(&ws));
+  // every partial slot the second stage reads is written by the first: nothing has to start at zero
   return colstats_run(agx::as_stream(stream), x, ldx, N, G, mean, std, ws, chunks);
 }
 

@@ -260,6 +260,17 @@ int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_dev, int32_t
 int64_t agx_colstats_ws_doubles(int32_t N, int32_t G);
 int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G, float *mean,
                  float *std, double *ws, int64_t ws_doubles);
+/* agx_colstats without a workspace argument and without any allocation.  NO COUNTERPART IN THE
+ * REFERENCE: it exists for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  The per-chunk partial sums live
+ * in a static device array of AGX_COLSTATS_NOALLOC_DOUBLES doubles (2 MiB per GPU, held until the
+ * process ends); G <= AGX_COLSTATS_NOALLOC_MAX_G, larger G is rejected with AGX_E_INVALID.  Same
+ * kernels and chunking as agx_colstats => bit-identical mean / std.  Calls that overlap on one GPU
+ * (different streams or threads) share that array and RACE: serialise them.                      */
+#define AGX_COLSTATS_NOALLOC_MAX_G 65536
+#define AGX_COLSTATS_NOALLOC_DOUBLES 262144
+int agx_colstats_noalloc(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
+                         float *mean, float *std);
 /* out = (x - mean) / std  (utils.py:268, 819) */
 int agx_standardize(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,
                     const float *mean, const float *std, float *out, int32_t ldo);
