@@ -290,7 +290,8 @@ bool tail_ok(const agx_cgan *h, int rows) {
   static const bool off = getenv("AGX_NO_TAIL") != nullptr;
   // (any batch: at 512 rows the tails still beat reduce + Dense + Dense(1) launches, 176.6 k vs 172.0 k samples/s)
   static const int max_rows = getenv("AGX_TAIL_MAX_ROWS") ? atoi(getenv("AGX_TAIL_MAX_ROWS")) : 1 << 30;
-  return !off && m.n_layers == 3 && m.dims[1] <= 256 && m.dims[2] <= 256 && rows <= max_rows;
+  // (mode 1 zeroes the covariate columns of a row with one 256-thread group: ncov <= 256)
+  return !off && m.n_layers == 3 && m.dims[1] <= 256 && m.dims[2] <= 256 && h->ncov <= 256 && rows <= max_rows;
 }
 
 agx::TailArgs tail_args(agx_cgan *h, int splitk, int m_slab) {

@@ -21,8 +21,10 @@ Differences a caller can see (all additive):
     takes its shard and gradients are summed with one RCCL all-reduce per
     optimizer step.
 """
+import ast
 import math
 import os
+import weakref
 from types import SimpleNamespace
 
 import numpy as np
@@ -288,11 +290,28 @@ def load_model(path):
     if not os.path.exists(path) and os.path.exists(path + '.npz'):
         path = path + '.npz'
     with np.load(path, allow_pickle=False) as f:
-        cfg = eval(str(f['__config__']), {'__builtins__': {}}, {})  # literal dict written by save()
+        cfg = ast.literal_eval(str(f['__config__']))   # literal dict written by save(); never evaluated as code
         ws = [f['w%03d' % i] for i in range(len(f.files) - 1)]
-    cls = Generator if cfg.pop('kind') == 'gen' else Critic
+    cfg = _check_model_config(cfg)
+    cls = Generator if cfg['kind'] == 'gen' else Critic
     return cls(cfg['x_dim'], cfg['vocab_sizes'], cfg['nb_numeric'], cfg['h_dims'], cfg['z_dim'],
-               slope=cfg.get('slope', 0.0), weights=ws)
+               slope=cfg['slope'], weights=ws)
+
+
+def _check_model_config(cfg):
+    """Keys and types of a saved model's config (a file is untrusted input)."""
+    if not isinstance(cfg, dict):
+        raise ValueError('model file: __config__ is not a dict')
+    isint = lambda v: isinstance(v, int) and not isinstance(v, bool)
+    intlist = lambda v: isinstance(v, (list, tuple)) and all(isint(a) and a > 0 for a in v)
+    ok = (cfg.get('kind') in ('gen', 'disc') and isint(cfg.get('x_dim')) and cfg['x_dim'] > 0
+          and isint(cfg.get('z_dim')) and cfg['z_dim'] > 0 and isint(cfg.get('nb_numeric')) and cfg['nb_numeric'] >= 0
+          and intlist(cfg.get('vocab_sizes')) and intlist(cfg.get('h_dims')) and len(cfg['h_dims']) >= 1
+          and isinstance(cfg.get('slope', 0.0), (int, float)))
+    if not ok:
+        raise ValueError('model file: malformed __config__ %r' % (cfg,))
+    return dict(kind=cfg['kind'], x_dim=cfg['x_dim'], z_dim=cfg['z_dim'], nb_numeric=cfg['nb_numeric'],
+                vocab_sizes=list(cfg['vocab_sizes']), h_dims=list(cfg['h_dims']), slope=float(cfg.get('slope', 0.0)))
 
 
 # ---------------------------------------------------------------------------
@@ -408,10 +427,10 @@ class RMSprop:
         self.iterations = 0
 
     def slot(self, net):
-        rms = self._state.get(id(net))
-        if rms is None:
-            rms = self._state[id(net)] = _dev.zeros(net.n_flat)
-        return rms
+        ent = self._state.get(id(net))
+        if ent is None or ent[0]() is not net:     # id() of a dead net may be reused: never hand its slot to another net
+            ent = self._state[id(net)] = (weakref.ref(net), _dev.zeros(net.n_flat))
+        return ent[1]
 
     def apply(self, net, grad_scale=1.0):
         lib = _lib.load()
@@ -421,7 +440,7 @@ class RMSprop:
         self.iterations += 1
 
     def state_arrays(self, net):
-        return {'rms': net._unflatten(self._state[id(net)].cpu().numpy())}
+        return {'rms': net._unflatten(self.slot(net).cpu().numpy())}
 
 
 class Adam:
@@ -436,10 +455,10 @@ class Adam:
         self.iterations = 0
 
     def slot(self, net):
-        st = self._state.get(id(net))
-        if st is None:
-            st = self._state[id(net)] = [_dev.zeros(net.n_flat), _dev.zeros(net.n_flat), 0]
-        return st
+        ent = self._state.get(id(net))
+        if ent is None or ent[0]() is not net:
+            ent = self._state[id(net)] = (weakref.ref(net), [_dev.zeros(net.n_flat), _dev.zeros(net.n_flat), 0])
+        return ent[1]
 
     def lr_t(self, t):
         return self.learning_rate * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
@@ -454,7 +473,7 @@ class Adam:
         self.iterations += 1
 
     def state_arrays(self, net):
-        st = self._state[id(net)]
+        st = self.slot(net)
         return {'m': net._unflatten(st[0].cpu().numpy()), 'v': net._unflatten(st[1].cpu().numpy())}
 
 
@@ -467,6 +486,7 @@ tfk.optimizers = SimpleNamespace(RMSprop=RMSprop, Adam=Adam)
 
 class _Pair:
     """C-side step context of one (generator, critic) pair: descriptor + workspace."""
+    MAX_GRAPHS = 16
 
     def __init__(self, gen, disc, max_batch, max_steps=6):
         lib = _lib.load()
@@ -539,13 +559,23 @@ class _Pair:
         """Capture (once per key) the whole loop iteration of tf_utils.py:316-323 as a hipGraph
         (split=True: one graph per segment between the gradient all-reduces of a data-parallel run)."""
         Bg = int(batch_global) if batch_global else B
-        key = (B, nb_critic, float(gp_weight), int(seed), id(gen_opt), id(disc_opt), gen_opt.learning_rate,
-               disc_opt.learning_rate, id(aug_d), id(aug_g), Bg, int(row_lo), bool(split))
+        hyper = ((gen_opt.rho, disc_opt.rho) if type(disc_opt) is RMSprop else
+                 (gen_opt.beta_1, gen_opt.beta_2, disc_opt.beta_1, disc_opt.beta_2))
+        key = (B, nb_critic, float(gp_weight), int(seed), id(gen_opt), id(disc_opt), type(disc_opt).__name__,
+               gen_opt.learning_rate, disc_opt.learning_rate, gen_opt.epsilon, disc_opt.epsilon, hyper,
+               id(aug_d), id(aug_g), Bg, int(row_lo), bool(split))
         g = self._graphs.get(key)
         if g is None:
             lib = _lib.load()
             a = self._iter_args(gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, seed, aug_d, aug_g, Bg, row_lo, split)
-            self._keep[key] = (aug_d, aug_g)
+            # the graph bakes in the device addresses of the optimizer slots and the augmentation constants:
+            # hold them (and the optimizer objects whose id() is in the key) for as long as the graph lives
+            self._keep[key] = (aug_d, aug_g, gen_opt, disc_opt, gen_opt.slot(gen), disc_opt.slot(disc))
+            while len(self._graphs) >= self.MAX_GRAPHS:     # train() builds fresh optimizers per call: bound the cache
+                old = next(iter(self._graphs))
+                torch.cuda.synchronize()
+                lib.agx_cgan_iter_destroy(self._graphs.pop(old))
+                self._keep.pop(old, None)
             g = _lib.C.c_void_p()
             side = torch.cuda.Stream()          # capture needs a non-default stream
             side.wait_stream(torch.cuda.current_stream())
@@ -564,6 +594,7 @@ class _Pair:
         for g in self._graphs.values():
             lib.agx_cgan_iter_destroy(g)
         self._graphs.clear()
+        self._keep.clear()
 
     def __del__(self):
         try:
@@ -577,12 +608,16 @@ class _Pair:
 
 
 def _pair(gen, disc, batch, steps=6):
-    p = gen._pair.get(id(disc))
+    ent = gen._pair.get(id(disc))
+    p = ent[1] if ent is not None and ent[0]() is disc else None   # a dead critic's id() may have been reused
     if p is None or p.max_batch < batch or p.max_steps < steps:
         _dev.device()
         if p is not None:
             batch, steps = max(batch, p.max_batch), max(steps, p.max_steps)
-        p = gen._pair[id(disc)] = _Pair(gen, disc, max(batch, 32), max(steps, 6))
+        p = _Pair(gen, disc, max(batch, 32), max(steps, 6))
+        for k in [k for k, (ref, _) in gen._pair.items() if ref() is None]:
+            del gen._pair[k]
+        gen._pair[id(disc)] = (weakref.ref(disc), p)
     return p
 
 
@@ -601,10 +636,13 @@ def _aug_constants(tag, key, p_aug, norm_scale, bs, nb_genes, rows=None):
     """The reference draws augmentation masks/noise with NumPy INSIDE ``@tf.function``
     (tf_utils.py:202, :209-210, :240, :247), so they are constants of each trace
     (one per input shape).  Same here: drawn once per (function, models, batch shape)
-    with the same NumPy calls in the same order, then reused."""
-    k = (tag,) + key
+    with the same NumPy calls in the same order, then reused.  `key` holds weak references to the
+    two models (never their id(): a freed model's id can be handed to a new one) and the shape."""
+    k = (tag, p_aug, norm_scale, nb_genes) + key
     c = _TRACE_CONSTS.get(k)
     if c is None:
+        while len(_TRACE_CONSTS) >= 64:            # bounded: notebooks rebuild models again and again
+            _TRACE_CONSTS.pop(next(iter(_TRACE_CONSTS)))
         augs = np.random.binomial(1, p_aug, bs)
         if tag == 'disc':
             nf = np.random.normal(0, norm_scale, nb_genes)
@@ -655,7 +693,7 @@ def train_disc(x, z, cc, nc, gen, disc, disc_opt, grad_penalty_weight=10, p_aug=
     a.gp_weight = float(grad_penalty_weight)
     keep = None
     if aug is None and p_aug:
-        aug = _aug_constants('disc', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
+        aug = _aug_constants('disc', (weakref.ref(gen), weakref.ref(disc), B), p_aug, norm_scale, B, gen.x_dim)
     if aug is not None:
         keep = (_dev.to_dev(aug['mask']).reshape(-1), _dev.to_dev(aug['noise_fake']).reshape(-1),
                 _dev.to_dev(aug['noise_real']))
@@ -684,7 +722,7 @@ def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None,
     a = _step_args(pair, z, cc, nc, B, Bg, losses)
     keep = None
     if aug is None and p_aug:
-        aug = _aug_constants('gen', (id(gen), id(disc), B), p_aug, norm_scale, B, gen.x_dim)
+        aug = _aug_constants('gen', (weakref.ref(gen), weakref.ref(disc), B), p_aug, norm_scale, B, gen.x_dim)
     if aug is not None:
         keep = (_dev.to_dev(aug['mask']).reshape(-1), _dev.to_dev(aug['noise']))
         a.aug_mask, a.aug_noise_fake = ptr(keep[0]), ptr(keep[1])
@@ -748,8 +786,8 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
     aug_d = aug_g = None
     if p_aug:   # same per-trace constants, drawn in the order the reference's first calls would (:202-210, :240-247)
         rows = (row_lo, row_lo + B) if world > 1 else None
-        aug_d = _aug_constants('disc', (id(gen), id(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
-        aug_g = _aug_constants('gen', (id(gen), id(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
+        aug_d = _aug_constants('disc', (weakref.ref(gen), weakref.ref(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
+        aug_g = _aug_constants('gen', (weakref.ref(gen), weakref.ref(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
     g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, grad_penalty_weight, _rng.seed, aug_d, aug_g,
                              batch_global=Bg, row_lo=row_lo, split=world > 1)
     if type(disc_opt) is Adam:

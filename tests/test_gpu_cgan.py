@@ -85,6 +85,23 @@ def test_disc_step_with_augmentation_and_leaky_slope(gpu):
     _check_grads(gen.get_gradients(), [g.numpy() for g in want])
 
 
+def test_more_than_256_covariate_columns_take_the_generic_path(gpu):
+    """The fused critic-tail kernels zero the covariate columns of a row with one 256-thread group;
+    a critic with more covariate columns (n_num + sum of embedding widths) must fall back to the
+    generic launch sequence instead of failing."""
+    p = make_problem(B=6, G=40, H=(32, 16), n_num=300, num_zero=False, seed=13)
+    T, gen, disc = _models(p)
+    loss = T.train_disc(_f32(p, 'x'), _f32(p, 'z'), p['cc'], _f32(p, 'nc'), gen, disc, T.RMSprop(5e-4),
+                        alpha=_f32(p, 'alpha'), apply=False)
+    wl, _, want = O.disc_loss_and_grads(t64(p['x']), t64(p['z']), tl(p['cc']), t64(p['nc']), O.to_torch(p['gp']),
+                                        O.to_torch(p['dp']), t64(p['alpha']))
+    assert abs(float(loss) - float(wl)) <= 1e-5 * max(1.0, abs(float(wl)))
+    _check_grads(disc.get_gradients(), [g.numpy() for g in want])
+    T.set_seed(3)
+    dl, gl = T.train_iteration(_f32(p, 'x'), p['cc'], _f32(p, 'nc'), gen, disc, T.RMSprop(5e-4), T.RMSprop(5e-4), 2)
+    assert np.isfinite(float(dl)) and np.isfinite(float(gl))
+
+
 def test_leaky_slope_matches_closed_form(gpu):
     """slope > 0 (north_star's LeakyReLU option) against the NumPy restatement of the same backward."""
     from oracle import cgan_closed_form as CF
@@ -117,35 +134,43 @@ def test_weights_after_steps(gpu, opt):
 
     RMSprop/Adam divide by sqrt(EMA(g^2)) + 1e-7, so an entry whose gradient is ~1e-7 turns an fp32
     rounding difference into an O(lr) difference of its update ('RMSprop
-    sensitivity').  Stated tolerance: 99.9 % of all weights within 2e-6, every weight within
-    n_steps * lr * sqrt(10) (the largest possible RMSprop displacement)."""
+    sensitivity').  The check is therefore a quantile: 99.9 % of all weights within 2e-6 of the fp64
+    oracle, and (tie-breaker) that quantile not worse than 4x the fp32 oracle's own distance from
+    the fp64 oracle + 1e-7.  The maximum is only printed: any optimizer trajectory satisfies an
+    O(steps * lr) bound, so asserting one would check nothing."""
     p = make_problem(B=12, G=61, H=(24, 16), seed=31)
     T, gen, disc = _models(p)
     lr = 5e-4
     mk = (lambda: T.RMSprop(lr)) if opt == 'rmsprop' else (lambda: T.Adam(lr))
     mko = (lambda: O.RMSprop(lr)) if opt == 'rmsprop' else (lambda: O.Adam(lr))
     go, do = mk(), mk()
+    p['x'] = _f32(p, 'x').astype(np.float64)        # both oracles see the fp32 inputs the GPU sees
     tg, td = O.to_torch(p['gp']), O.to_torch(p['dp'])
-    ogo, odo = mko(), mko()
+    sg, sd = O.to_torch(p['gp'], dtype=torch.float32), O.to_torch(p['dp'], dtype=torch.float32)
+    ogo, odo, sgo, sdo = mko(), mko(), mko(), mko()
+    t32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
     rs = np.random.RandomState(5)
     losses, olosses = [], []
     n_it = 5
     for it in range(n_it):
         for _ in range(5):
-            z, al = rs.randn(12, p['Z']), rs.rand(12, 1)
-            losses.append(float(T.train_disc(_f32(p, 'x'), z.astype(np.float32), p['cc'], _f32(p, 'nc'), gen, disc, do,
-                                             alpha=al.astype(np.float32))))
+            z, al = rs.randn(12, p['Z']).astype(np.float32), rs.rand(12, 1).astype(np.float32)
+            losses.append(float(T.train_disc(_f32(p, 'x'), z, p['cc'], _f32(p, 'nc'), gen, disc, do, alpha=al)))
             olosses.append(float(O.train_disc(t64(p['x']), t64(z), tl(p['cc']), t64(p['nc']), tg, td, odo, t64(al))[0]))
-        z = rs.randn(12, p['Z'])
-        losses.append(float(T.train_gen(z.astype(np.float32), p['cc'], _f32(p, 'nc'), gen, disc, go)))
+            O.train_disc(t32(p['x']), t32(z), tl(p['cc']), t32(p['nc']), sg, sd, sdo, t32(al))
+        z = rs.randn(12, p['Z']).astype(np.float32)
+        losses.append(float(T.train_gen(z, p['cc'], _f32(p, 'nc'), gen, disc, go)))
         olosses.append(float(O.train_gen(t64(z), tl(p['cc']), t64(p['nc']), tg, td, ogo)[0]))
+        O.train_gen(t32(z), tl(p['cc']), t32(p['nc']), sg, sd, sgo)
     np.testing.assert_allclose(losses, olosses, rtol=2e-4, atol=2e-4)
-    for net, tp, steps in ((gen, tg, n_it), (disc, td, 5 * n_it)):
-        got = np.concatenate([w.reshape(-1) for w in net.get_weights()])
-        want = np.concatenate([t.detach().numpy().reshape(-1) for t in O.param_list(tp)])
-        err = np.abs(got - want)
-        assert np.quantile(err, 0.999) < 2e-6, np.quantile(err, 0.999)
-        assert err.max() <= steps * lr * np.sqrt(10) + 1e-6, err.max()
+    flat = lambda tp: np.concatenate([t.detach().numpy().astype(np.float64).reshape(-1) for t in O.param_list(tp)])
+    for net, tp, sp in ((gen, tg, sg), (disc, td, sd)):
+        got = np.concatenate([w.reshape(-1) for w in net.get_weights()]).astype(np.float64)
+        e64, o32 = np.abs(got - flat(tp)), np.abs(flat(sp) - flat(tp))
+        q, qo = np.quantile(e64, 0.999), np.quantile(o32, 0.999)
+        print('%s %s: q999 gpu-f64 %.3g, f32 oracle-f64 %.3g; max %.3g / %.3g' % (opt, net.kind, q, qo, e64.max(), o32.max()))
+        assert q < 2e-6, q
+        assert q <= 4 * qo + 1e-7, (q, qo)
 
 
 def _noise_factory():

@@ -130,7 +130,8 @@ def test_captured_iteration_matches_oracle(gpu, name):
     pair = T._pair(gen, disc, c['B'], nbc + 1)
     ad = ag = None
     if c['p_aug']:
-        key = (id(gen), id(disc), c['B'], 0, c['B'])
+        import weakref
+        key = (weakref.ref(gen), weakref.ref(disc), c['B'], 0, c['B'])
         ad = T._aug_constants('disc', key, c['p_aug'], 0.5, c['B'], c['G'])
         ag = T._aug_constants('gen', key, c['p_aug'], 0.5, c['B'], c['G'])
     g = pair.iteration_graph(gen, disc, go, do, c['B'], nbc, 10.0, seed, ad, ag)
