@@ -79,6 +79,30 @@ def allreduce_sum(t):
     return t
 
 
+def reduce_scatter_sum(out, inp):
+    """out = this rank's 1/R slice of the sum of inp over ranks (RCCL reduce-scatter; via the host under gloo)."""
+    import torch.distributed as dist
+    if inp.is_cuda and dist.get_backend() == 'gloo':
+        ho, hi = out.cpu(), inp.cpu()
+        dist.reduce_scatter_tensor(ho, hi)
+        out.copy_(ho)
+    else:
+        dist.reduce_scatter_tensor(out, inp)
+    return out
+
+
+def all_gather(out, inp):
+    """out = concatenation of every rank's inp (RCCL all-gather; via the host under gloo)."""
+    import torch.distributed as dist
+    if inp.is_cuda and dist.get_backend() == 'gloo':
+        ho, hi = out.cpu(), inp.cpu()
+        dist.all_gather_into_tensor(ho, hi)
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+    return out
+
+
 class DeviceArray:
     """Result living in HBM; converts lazily (the only host sync is the conversion)."""
 

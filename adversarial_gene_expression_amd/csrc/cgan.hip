@@ -745,6 +745,8 @@ bool chain_input(const agx_cgan *h, const agx_iter_args_t *a) {
 //   k (1..nbc-1): critic RMSprop, critic gradients of step k
 //   nbc: critic RMSprop, generator gradients          nbc+1: generator RMSprop
 // (nbc == 0: segment 0 holds the generator gradients).
+// split == 2: the segments hold NO optimizer launch (nbc+1 segments): the caller reduce-scatters the
+// gradient buffer, updates its 1/R shard of the parameters and all-gathers them between segments.
 int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int seg, int64_t *draws) {
   const int B = a->B, Z = h->cfg.z_dim, nbc = a->nb_critic, S = nbc + 1, G = h->G;
   const int Bg = a->B_global > 0 ? a->B_global : B, lo = a->row_lo;
@@ -881,7 +883,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
       AGX_TRY(critic_core(h, st, h->scat, B, Bg, h->abuf + (size_t)k * B, a->gp_weight,
                           a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dk : nullptr));
     }
-    if (in_seg(k + 1)) {
+    if (in_seg(k + 1) && a->split != 2) {
       if (adam) AGX_TRY(agx::opt_adam_dev_lr(st, h->dp, h->dg, a->disc_m, a->disc_v, dm.n_flat, h->lrdev + k, a->beta1, a->beta2, a->eps));
       else if (fuse_d && rest_d) {}   // updated by the layer-1 product's launch
       else if (fuse_d) AGX_TRY(agx::opt_rmsprop_hole(st, h->dp, h->dg, a->disc_rms, dm.n_flat, dhole_lo, dhole_hi, a->lr_disc, a->rho, a->eps));
@@ -896,7 +898,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc,
                      fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));
   }
-  if (in_seg(nbc + 1)) {
+  if (in_seg(nbc + 1) && a->split != 2) {
     if (adam) AGX_TRY(agx::opt_adam_dev_lr(st, h->gp, h->gg, a->gen_m, a->gen_v, gm0.n_flat, h->lrdev + nbc, a->beta1, a->beta2, a->eps));
     else if (fuse_g && rest) {}     // updated by the output-layer product's launch
     else if (fuse_g) AGX_TRY(agx::opt_rmsprop_hole(st, h->gp, h->gg, a->gen_rms, gm0.n_flat, ghole_lo, ghole_hi, a->lr_gen, a->rho, a->eps));
@@ -917,7 +919,8 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
                 "agx_cgan_iter_capture: rows [%d, %d) outside the global batch %d", a->row_lo, a->row_lo + a->B, a->B_global);
   AGX_CHECK_ARG(a->B_global != 0 || a->row_lo == 0, "agx_cgan_iter_capture: row_lo without B_global");
   AGX_CHECK_ARG(a->opt_kind == 0 || a->opt_kind == 1, "agx_cgan_iter_capture: opt_kind %d", a->opt_kind);
-  AGX_CHECK_ARG(a->opt_kind == 1 ? (a->disc_m && a->disc_v && a->gen_m && a->gen_v) : (a->disc_rms && a->gen_rms),
+  AGX_CHECK_ARG(a->split >= 0 && a->split <= 2, "agx_cgan_iter_capture: split %d", a->split);
+  AGX_CHECK_ARG(a->split == 2 || (a->opt_kind == 1 ? (a->disc_m && a->disc_v && a->gen_m && a->gen_v) : (a->disc_rms && a->gen_rms)),
                 "agx_cgan_iter_capture: optimizer slots missing");
   AGX_CHECK_ARG(!a->aug_mask_disc || (a->aug_noise_fake && a->aug_noise_real), "agx_cgan_iter_capture: critic aug noise missing");
   AGX_CHECK_ARG(!a->aug_mask_gen || a->aug_noise_gen, "agx_cgan_iter_capture: generator aug noise missing");
@@ -931,10 +934,10 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   AGX_CHECK_ARG(g, "agx_cgan_iter_capture: out of host memory");
   g->h = h; g->B = a->B; g->nb_critic = a->nb_critic;
   g->snap = !a->split && !a->disc_losses && !a->gen_losses;
-  g->adam = a->opt_kind == 1;
+  g->adam = a->opt_kind == 1 && a->split != 2;   // split == 2: the caller's optimizer launches take their step size from the host
   g->chainx = chain_input(h, a);
   g->lrs.n = 0;
-  const int nseg = a->split ? a->nb_critic + 2 : 1;
+  const int nseg = a->split == 2 ? a->nb_critic + 1 : (a->split ? a->nb_critic + 2 : 1);
   for (int s = 0; s < nseg; ++s) {
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) {

@@ -36,7 +36,8 @@ from ._dev import DeviceArray, ptr
 tfk = SimpleNamespace()  # populated below with .optimizers.{RMSprop, Adam}
 
 CHECKPOINTS_DIR = '../checkpoints/'
-_LOSS_SLOTS = 64  # floats appended to every flat gradient buffer (loss scalars ride the all-reduce)
+_LOSS_SLOTS = 64  # floats appended to every flat gradient buffer (loss scalars ride the gradient exchange)
+_EXCH_SLACK = 1024  # further floats so that [0, n_flat + slots) rounds up to a multiple of 4 * world (world <= 256)
 
 
 def limit_gpu(gpu_idx=0, mem=2 * 1024):
@@ -115,8 +116,12 @@ class _Net:
         out = self.x_dim if self.kind == 'gen' else 1
         self.dims = [lead + self.nb_numeric + sum(self.emb_dims)] + self.h_dims + [out]
         self._layout()
-        self.params = _dev.zeros(self.n_flat)
-        self.grads = _dev.zeros(self.n_flat + _LOSS_SLOTS)
+        # flat buffers; the tails (loss slots + slack) exist for the data-parallel exchange (_dp_update)
+        self._pbuf = _dev.zeros(self.n_flat + _LOSS_SLOTS + _EXCH_SLACK)
+        self._gbuf = _dev.zeros(self.n_flat + _LOSS_SLOTS + _EXCH_SLACK)
+        self.params = self._pbuf[:self.n_flat]
+        self.grads = self._gbuf[:self.n_flat + _LOSS_SLOTS]
+        self._shards = {}
         self.set_weights(weights if weights is not None else self._initial_weights(seed))
         self._pair = {}
         # Keras-like introspection used by the reference (tf_utils.py:201, :371)
@@ -439,8 +444,16 @@ class RMSprop:
                                        self.learning_rate, self.rho, self.epsilon, grad_scale), 'agx_opt_rmsprop')
         self.iterations += 1
 
+    def apply_range(self, net, lo, n, g):
+        """Update parameters [lo, lo + n) from the gradient slice g (a rank's shard of a data-parallel step)."""
+        lib = _lib.load()
+        rms = self.slot(net)
+        _lib.check(lib.agx_opt_rmsprop(_dev.stream(), net.params.data_ptr() + 4 * lo, ptr(g), rms.data_ptr() + 4 * lo, n,
+                                       self.learning_rate, self.rho, self.epsilon, 1.0), 'agx_opt_rmsprop')
+        self.iterations += 1
+
     def state_arrays(self, net):
-        return {'rms': net._unflatten(self.slot(net).cpu().numpy())}
+        return {'rms': net._unflatten(_gathered_slot(net, self.slot(net)).cpu().numpy())}
 
 
 class Adam:
@@ -472,9 +485,19 @@ class Adam:
                                     lr_t, self.beta_1, self.beta_2, self.epsilon, grad_scale), 'agx_opt_adam')
         self.iterations += 1
 
+    def apply_range(self, net, lo, n, g):
+        lib = _lib.load()
+        st = self.slot(net)
+        st[2] += 1
+        _lib.check(lib.agx_opt_adam(_dev.stream(), net.params.data_ptr() + 4 * lo, ptr(g), st[0].data_ptr() + 4 * lo,
+                                    st[1].data_ptr() + 4 * lo, n, self.lr_t(st[2]), self.beta_1, self.beta_2, self.epsilon,
+                                    1.0), 'agx_opt_adam')
+        self.iterations += 1
+
     def state_arrays(self, net):
         st = self.slot(net)
-        return {'m': net._unflatten(st[0].cpu().numpy()), 'v': net._unflatten(st[1].cpu().numpy())}
+        return {'m': net._unflatten(_gathered_slot(net, st[0]).cpu().numpy()),
+                'v': net._unflatten(_gathered_slot(net, st[1]).cpu().numpy())}
 
 
 tfk.optimizers = SimpleNamespace(RMSprop=RMSprop, Adam=Adam)
@@ -517,7 +540,9 @@ class _Pair:
         a.B, a.nb_critic, a.gp_weight = B, nb_critic, gp_weight
         a.lr_disc, a.lr_gen = disc_opt.learning_rate, gen_opt.learning_rate
         a.eps = disc_opt.epsilon
-        if type(disc_opt) is Adam:
+        if int(split) == 2:
+            pass     # no optimizer launch inside the segments: the slots stay with the caller (_dp_update)
+        elif type(disc_opt) is Adam:
             a.opt_kind, a.beta1, a.beta2 = 1, disc_opt.beta_1, disc_opt.beta_2
             sd, sg = disc_opt.slot(disc), gen_opt.slot(gen)
             a.disc_m, a.disc_v, a.gen_m, a.gen_v = ptr(sd[0]), ptr(sd[1]), ptr(sg[0]), ptr(sg[1])
@@ -531,7 +556,7 @@ class _Pair:
         if aug_g is not None:
             a.aug_mask_gen, a.aug_noise_gen = ptr(aug_g['mask']), ptr(aug_g['noise'])
         if split or Bg != B:
-            a.B_global, a.row_lo, a.split = Bg, int(row_lo), int(bool(split))
+            a.B_global, a.row_lo, a.split = Bg, int(row_lo), int(split)
             # loss scalars go to the slots behind the gradients, so they ride the all-reduce
             a.disc_losses = disc.grads.data_ptr() + 4 * disc.n_flat
             a.gen_losses = gen.grads.data_ptr() + 4 * gen.n_flat
@@ -563,7 +588,7 @@ class _Pair:
                  (gen_opt.beta_1, gen_opt.beta_2, disc_opt.beta_1, disc_opt.beta_2))
         key = (B, nb_critic, float(gp_weight), int(seed), id(gen_opt), id(disc_opt), type(disc_opt).__name__,
                gen_opt.learning_rate, disc_opt.learning_rate, gen_opt.epsilon, disc_opt.epsilon, hyper,
-               id(aug_d), id(aug_g), Bg, int(row_lo), bool(split))
+               id(aug_d), id(aug_g), Bg, int(row_lo), int(split))
         g = self._graphs.get(key)
         if g is None:
             lib = _lib.load()
@@ -627,6 +652,65 @@ def _world():
 
 def _allreduce_grads(net):
     _dev.allreduce_sum(net.grads)  # RCCL sum over xGMI; the loss slots behind the gradients ride along
+
+
+def _exchange_layout(net, world, rank):
+    """(total, shard, lo): the flat buffers' first `total` floats (gradients + loss slots, rounded up to a
+    multiple of 4 * world inside the slack) are dealt to the ranks in equal contiguous shards."""
+    q = 4 * world
+    total = (net.n_flat + _LOSS_SLOTS + q - 1) // q * q
+    if total > net._gbuf.numel():
+        raise ValueError('world size %d too large for the exchange slack' % world)
+    shard = total // world
+    return total, shard, rank * shard
+
+
+def _dp_update(net, opt):
+    """Data-parallel optimizer step over xGMI: reduce-scatter the flat gradient buffer (each rank receives
+    the sum of its 1/R shard), apply the optimizer to that shard only (the 94 MB RMSprop pass of the GTEx
+    critic becomes 94/R MB per GPU; the optimizer slots of the other shards are never touched), all-gather
+    the parameters.  Same bytes on the links as one all-reduce of the gradients.  The loss scalars sit in the
+    slots behind the gradients: their sums travel back in the parameter buffer's tail (net._pbuf[n_flat:])."""
+    world, rank = _world()
+    total, shard, lo = _exchange_layout(net, world, rank)
+    key = (world, rank)
+    bufs = net._shards.get(key)
+    if bufs is None:
+        bufs = net._shards[key] = (torch.empty(shard, dtype=net._gbuf.dtype, device=net._gbuf.device),
+                                   torch.empty(shard, dtype=net._pbuf.dtype, device=net._pbuf.device))
+    g_sh, p_sh = bufs
+    _dev.reduce_scatter_sum(g_sh, net._gbuf[:total])
+    n_upd = max(0, min(lo + shard, net.n_flat) - lo)
+    if n_upd:
+        opt.apply_range(net, lo, n_upd, g_sh)
+    else:
+        opt.iterations += 1
+        if type(opt) is Adam:
+            opt.slot(net)[2] += 1
+    if lo + shard > net.n_flat:           # loss slots (+ padding): the reduced values themselves are what travels
+        a = max(lo, net.n_flat)
+        net._pbuf[a:lo + shard].copy_(g_sh[a - lo:])
+    p_sh.copy_(net._pbuf[lo:lo + shard])
+    _dev.all_gather(net._pbuf[:total], p_sh)
+
+
+def _gathered_slot(net, slot):
+    """Optimizer slot with every rank's shard filled in (each rank only ever updates its own shard)."""
+    world, rank = _world()
+    if world == 1:
+        return slot
+    total, shard, lo = _exchange_layout(net, world, rank)
+    full = torch.zeros(total, dtype=slot.dtype, device=slot.device)
+    mine = torch.zeros(shard, dtype=slot.dtype, device=slot.device)
+    n = max(0, min(lo + shard, net.n_flat) - lo)
+    mine[:n] = slot[lo:lo + n]
+    _dev.all_gather(full, mine)
+    return full[:net.n_flat]
+
+
+def _reduced_loss(net, idx):
+    """Loss scalar `idx` of the last data-parallel step (summed over ranks)."""
+    return DeviceArray(net._pbuf[net.n_flat + idx:net.n_flat + idx + 1].clone())
 
 
 _TRACE_CONSTS = {}
@@ -699,6 +783,9 @@ def train_disc(x, z, cc, nc, gen, disc, disc_opt, grad_penalty_weight=10, p_aug=
                 _dev.to_dev(aug['noise_real']))
         a.aug_mask, a.aug_noise_fake, a.aug_noise_real = ptr(keep[0]), ptr(keep[1]), ptr(keep[2])
     _lib.check(lib.agx_cgan_disc_grads(pair.handle, _dev.stream(), a), 'agx_cgan_disc_grads')
+    if world > 1 and apply:
+        _dp_update(disc, disc_opt)
+        return _reduced_loss(disc, 2)
     if world > 1:
         _allreduce_grads(disc)
     if apply:
@@ -727,6 +814,9 @@ def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None,
         keep = (_dev.to_dev(aug['mask']).reshape(-1), _dev.to_dev(aug['noise']))
         a.aug_mask, a.aug_noise_fake = ptr(keep[0]), ptr(keep[1])
     _lib.check(lib.agx_cgan_gen_grads(pair.handle, _dev.stream(), a), 'agx_cgan_gen_grads')
+    if world > 1 and apply:
+        _dp_update(gen, gen_opt)
+        return _reduced_loss(gen, 0)
     if world > 1:
         _allreduce_grads(gen)
     if apply:
@@ -766,8 +856,9 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
 
     Under torch.distributed (one process per GPU) ``x`` holds this rank's rows
     ``[row_lo, row_lo + len(x))`` of a global batch of ``batch_global`` rows: the iteration is
-    captured as nb_critic+2 graph segments with one RCCL sum all-reduce of the flat gradient buffer
-    between them; draws are the global batch's, so R ranks reproduce the one-GPU big-batch run.
+    captured as nb_critic+1 gradient segments; between them the flat gradient buffer is reduce-scattered
+    over RCCL, each rank applies the optimizer to its 1/R shard and the parameters are all-gathered
+    (``_dp_update``); draws are the global batch's, so R ranks reproduce the one-GPU big-batch run.
     RMSprop (the reference default) or Adam on both nets; ``train`` falls back to the eager step
     functions otherwise."""
     lib = _lib.load()
@@ -789,8 +880,8 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
         aug_d = _aug_constants('disc', (weakref.ref(gen), weakref.ref(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
         aug_g = _aug_constants('gen', (weakref.ref(gen), weakref.ref(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
     g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, grad_penalty_weight, _rng.seed, aug_d, aug_g,
-                             batch_global=Bg, row_lo=row_lo, split=world > 1)
-    if type(disc_opt) is Adam:
+                             batch_global=Bg, row_lo=row_lo, split=2 if world > 1 else 0)
+    if type(disc_opt) is Adam and world == 1:
         lrs = _adam_step_sizes(gen, disc, gen_opt, disc_opt, nb_critic)
         _lib.check(lib.agx_cgan_iter_set_lr(g, lrs, nb_critic + 1), 'agx_cgan_iter_set_lr')
     if world == 1:
@@ -802,16 +893,19 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
     else:
         _lib.check(lib.agx_cgan_iter_stage(g, _dev.stream(), ptr(x), x.stride(0), ptr(cc), ptr(nc), _rng.offset),
                    'agx_cgan_iter_stage')
+        # nb_critic + 1 gradient segments; between them the exchange + sharded optimizer step (_dp_update)
         d_loss = None
-        for s in range(nb_critic + 2):
+        for s in range(nb_critic + 1):
             _lib.check(lib.agx_cgan_iter_launch_seg(g, _dev.stream(), s), 'agx_cgan_iter_launch_seg')
             if s < nb_critic:
-                _allreduce_grads(disc)
+                _dp_update(disc, disc_opt)
                 if s == nb_critic - 1:
-                    d_loss = DeviceArray(disc.grads[disc.n_flat + 2:disc.n_flat + 3].clone())
-            elif s == nb_critic:
-                _allreduce_grads(gen)
-        g_loss = DeviceArray(gen.grads[gen.n_flat:gen.n_flat + 1].clone())
+                    d_loss = _reduced_loss(disc, 2)
+            else:
+                _dp_update(gen, gen_opt)
+        g_loss = _reduced_loss(gen, 0)
+        _rng.offset += int(lib.agx_cgan_iter_rng_draws(g))
+        return d_loss, g_loss
     _rng.offset += int(lib.agx_cgan_iter_rng_draws(g))
     disc_opt.iterations += nb_critic
     gen_opt.iterations += 1
@@ -930,8 +1024,34 @@ def make_score_fn(x_test, cat_covs_test, num_covs_test):
     nc = _dev.to_dev(num_covs_test)
 
     def _score(gen):
-        return scorer(predict(cc, nc, gen, training=True).tensor)
+        return scorer(predict_sharded(cc, nc, gen))
     return _score
+
+
+def predict_sharded(cc, nc, gen, z=None):
+    """``predict`` with the test set's rows dealt across the ranks of a torch.distributed job (independent
+    samples: reference ``tf_utils.py:359-376`` is one full-batch forward): every rank runs the generator on
+    its contiguous row shard - the rows of the GLOBAL z draw, so the result equals the one-GPU ``predict`` -
+    and one all-gather assembles the [N, G] device matrix on every rank (what the tiled Gamma evaluation
+    consumes).  Outside a distributed job this is ``predict(..., training=True)``."""
+    world, rank = _world()
+    cc = _dev.to_dev(cc, torch.int32)
+    nc = _dev.to_dev(nc)
+    n = cc.shape[0]
+    if z is None:
+        z = random_normal([n, gen.input[0].shape[-1]])     # same stream position on every rank
+    z = _dev.to_dev(z)
+    if world == 1 or n < world:
+        return gen([z, cc, nc], training=True).tensor
+    per = (n + world - 1) // world
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    g = gen.x_dim
+    mine = torch.zeros((per, g), dtype=torch.float32, device=z.device)
+    if hi > lo:
+        mine[:hi - lo] = gen([z[lo:hi], cc[lo:hi], nc[lo:hi]], training=True).tensor
+    full = torch.empty((per * world, g), dtype=torch.float32, device=z.device)
+    _dev.all_gather(full.view(-1), mine.view(-1))
+    return full[:n]
 
 
 def predict(cc, nc, gen, z=None, training=False):

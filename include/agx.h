@@ -378,7 +378,10 @@ typedef struct agx_iter_args {
   const float *aug_mask_gen, *aug_noise_gen;
   /* data parallel (all 0 / NULL on one GPU): this rank holds rows [row_lo, row_lo+B) of a global  */
   /* batch of B_global rows; draws are the global batch's, means divide by B_global; split = 1      */
-  /* captures one graph per segment between gradient all-reduces (agx_cgan_iter_launch_seg);        */
+  /* captures one graph per segment between gradient all-reduces (agx_cgan_iter_launch_seg), the    */
+  /* optimizer launch at the head of the next segment; split = 2 captures nb_critic + 1 segments    */
+  /* WITHOUT optimizer launches (the caller reduce-scatters the gradients, updates its 1/R shard of */
+  /* the parameters and all-gathers them between segments; no optimizer slots needed here);         */
   /* disc_losses / gen_losses (device [4]) redirect the loss scalars, e.g. into slots that ride the */
   /* gradient all-reduce.                                                                           */
   int32_t B_global, row_lo, split;
@@ -403,9 +406,10 @@ int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter_args_t *a,
 int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
                          const int32_t *cat, const float *num, uint64_t rng_offset,
                          float *losses_out);
-/* Split form for data-parallel runs: stage once, then launch segments 0 .. num_segs-1 with a
- * sum all-reduce of the critic (after segments 0..nb_critic-1) or generator (after segment
- * nb_critic) gradient buffer in between (RCCL, issued by the caller on the same stream). */
+/* Split form for data-parallel runs: stage once, then launch segments 0 .. num_segs-1 with the
+ * exchange of the critic (after segments 0..nb_critic-1) or generator (after segment nb_critic)
+ * gradient buffer in between (RCCL, issued by the caller on the same stream): a sum all-reduce
+ * (split = 1) or reduce-scatter + sharded update + parameter all-gather (split = 2). */
 int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const float *x, int32_t ldx,
                         const int32_t *cat, const float *num, uint64_t rng_offset);
 int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g);

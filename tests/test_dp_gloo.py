@@ -67,3 +67,54 @@ def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), 'ok%d' % r)) for r in range(world))
+
+
+class _SgdStub:
+    """CPU stand-in for the HIP optimizers: same apply_range contract (parameters [lo, lo+n) from a shard)."""
+    def __init__(self):
+        self.iterations = 0
+
+    def apply_range(self, net, lo, n, g):
+        net.params[lo:lo + n] -= 0.5 * g[:n]
+        self.iterations += 1
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from adversarial_gene_expression_amd import tf_utils as T
+        for n_flat in (64, 192, 4096 + 64):      # first: the loss slots fall into the LAST rank's shard only
+            rs = np.random.RandomState(n_flat)
+            w0 = rs.randn(n_flat).astype(np.float32)
+            size = n_flat + T._LOSS_SLOTS + T._EXCH_SLACK
+            pbuf, gbuf = torch.zeros(size), torch.zeros(size)
+            pbuf[:n_flat] = torch.from_numpy(w0)
+            net = SimpleNamespace(n_flat=n_flat, _pbuf=pbuf, _gbuf=gbuf, params=pbuf[:n_flat],
+                                  grads=gbuf[:n_flat + T._LOSS_SLOTS], _shards={})
+            grs = [np.random.RandomState(1000 + r).randn(n_flat).astype(np.float32) for r in range(world)]
+            gbuf[:n_flat] = torch.from_numpy(grs[rank])
+            gbuf[n_flat + 2] = 1.5 + rank                 # this rank's share of the loss scalar
+            opt = _SgdStub()
+            T._dp_update(net, opt)
+            want = w0 - 0.5 * np.sum(grs, axis=0)
+            np.testing.assert_allclose(net.params.numpy(), want, rtol=1e-6, atol=1e-6)
+            assert float(T._reduced_loss(net, 2)) == sum(1.5 + r for r in range(world))
+            assert opt.iterations == 1
+            total, shard, lo = T._exchange_layout(net, world, rank)
+            assert total % (4 * world) == 0 and total >= n_flat + T._LOSS_SLOTS and shard * world == total
+        open(os.path.join(out_dir, 'ex%d' % rank), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_scatter_sharded_update_all_gather(tmp_path):
+    """tf_utils._dp_update on CPU tensors over gloo (2 and 3 ranks): reduce-scatter of the flat gradient
+    buffer, optimizer on the own shard, all-gather of the parameters == full-gradient update everywhere;
+    the loss scalars behind the gradients come back summed."""
+    for world in (2, 3):
+        d = tmp_path / ('w%d' % world)
+        d.mkdir()
+        mp.spawn(_exchange_worker, args=(world, _free_port(), str(d)), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(str(d), 'ex%d' % r)) for r in range(world))
