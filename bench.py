@@ -38,8 +38,10 @@ WORKLOADS = {
     # name: (G, vocab_sizes, n_num, h_dims, z_dim)
     'gtex': (18154, [15, 3], 1, [256, 256], 64),          # gtex_tcga_gan.py:11-18, notebook shapes
     'wide': (20000, [15, 3], 1, [1024, 1024], 64),        # BASELINE.json configs[4]
-    'ecoli': (4297, [6, 8, 5, 11, 5, 3, 5], 1, [128, 128], 10),
+    'ecoli': (4297, [6, 8, 5, 11, 5, 3, 5], 1, [128, 128], 10),       # BASELINE.json configs[0] (all genes)
+    'ecoli_crp': (1076, [6, 8, 5, 11, 5, 3, 5], 1, [128, 128], 10),   # as shipped: root_gene='CRP' (ecoli_gan.py:14)
 }
+P_AUG = {'ecoli': 0.25, 'ecoli_crp': 0.25}                # ecoli_gan.py:90; the GTEx script trains without augmentation
 
 
 def algorithmic_flops_per_iter(G, V, n, H, Z, B, nb_critic=5):
@@ -85,7 +87,7 @@ def prof_read_all(lib, _lib):
     return out
 
 
-def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
+def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True):
     import torch
     import torch.distributed as dist
     from adversarial_gene_expression_amd import _lib, tf_utils as T
@@ -100,13 +102,17 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
     Bg = B * world
 
     use_graph = not os.environ.get('AGX_BENCH_EAGER')
+    p_aug = P_AUG.get(workload, 0)
+    np.random.seed(0)      # augmentation constants (NumPy draws at first use, like the reference's trace constants)
+    last = [None]
 
     def iteration(i):
         s = slice((i % nbatches) * B, (i % nbatches + 1) * B)
         xb, cb, nb = x[s], cc[s], nc[s]
         if use_graph:      # the path train() takes: one hipGraph per iteration (N > 1: one graph segment
-            # between consecutive gradient all-reduces)
-            T.train_iteration(xb, cb, nb, gen, disc, gopt, dopt, nb_critic, batch_global=Bg, row_lo=rank * B)
+            # per gradient exchange)
+            last[0] = T.train_iteration(xb, cb, nb, gen, disc, gopt, dopt, nb_critic, p_aug=p_aug, batch_global=Bg,
+                                        row_lo=rank * B)
             return
         for _ in range(nb_critic):
             z = T.random_normal((B, Z))
@@ -154,26 +160,41 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
     iteration(0)                               # first call: workspace, graph capture
     sync()
     nprobe = 3
-    disc_prof = bracketed(-1, nprobe)          # discovery: which kernel class dominates?
-    dominant = max(disc_prof, key=lambda k: disc_prof[k]['ms'])
+    if roofline:
+        disc_prof = bracketed(-1, nprobe)          # discovery: which kernel class dominates?
+        dominant = max(disc_prof, key=lambda k: disc_prof[k]['ms'])
     dbg('probe done')
     lib.agx_prof_reset()
     # the W untimed warm-up steps run right in front of the timed region (the probe above leaves the
     # GPU idle between its bracketed launches; 3 % slower steps were measured straight after it)
+    # (batches are walked in sequence 1, 2, ... across warm-up and timed region, as train() walks the data set:
+    #  training twice in a row on one batch of this synthetic data drives the wide critic to a zero penalty slope,
+    #  whose NaN - tf_utils.py:169 has no epsilon - the fp64 oracle reproduces at the same step:
+    #  profiles/r02_wide_zero_slope_nan_matches_oracle.txt)
     for i in range(warmup):
-        iteration(i)
+        iteration(1 + i)
         dbg('warmup %d queued' % i)
     sync()
     dbg('warmup done')
     t0 = time.perf_counter()
     for i in range(steps):
-        iteration(i)
+        iteration(1 + warmup + i)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    final_losses = None
+    if last[0] is not None:   # the timed iterations computed something sane: losses of the last one, read after the clock stopped
+        final_losses = [float(last[0][0]), float(last[0][1])]
+        if not all(np.isfinite(v) for v in final_losses):
+            raise RuntimeError('bench: non-finite losses after the timed region: %r' % (final_losses,))
+    if not roofline:
+        res = dict(value=Bg * steps / dt, ms_per_step=dt / steps * 1e3, final_losses=final_losses)
+        del gen, disc, x
+        torch.cuda.empty_cache()
+        return res
     # dominant kernel, timed with HIP events on the launch stream right after the timed region
     # (a captured graph cannot host event brackets on ROCm 7.2, so the same iteration is replayed
     # through the eager entry points; profiles/ holds the rocprofv3 trace of the graph run itself)
@@ -191,12 +212,18 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5):
     else:
         ach = dom['bytes'] / dom['count'] / avg_s / 1e9
         roof = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS)
+    traffic, traffic_src = measured_traffic(dom['name'], B)
     roof.update(kernel=dom['name'], launches=dom['count'], avg_us=avg_s * 1e6, avg_us_bracketed=raw_us,
-                bracket_overhead_us=empty.value, traffic=measured_traffic(dom['name'], B))
+                bracket_overhead_us=empty.value, traffic=traffic, traffic_source=traffic_src,
+                algorithmic_per_launch=(dom['flops'] if mfma_bound else dom['bytes']) / dom['count'])
+    if dom['name'] == 'disc_dw_in' and world == 1 and B < 128:
+        # what the launch carries besides the product SURVEY 8(d) prices (NOT in `achieved`): the next step's
+        # generated rows copied into the other stacked-input buffer and the flat RMSprop of the other parameters
+        roof['carried_bytes_not_counted'] = 8.0 * B * G + 20.0 * (disc.n_flat - disc.dims[0] * disc.ldw[0])
     tot = sum(v['ms'] for v in disc_prof.values())
     breakdown = {v['name']: round(v['ms'] / nprobe * 1e3, 1) for v in sorted(disc_prof.values(), key=lambda v: -v['ms'])}
     flops_iter = algorithmic_flops_per_iter(G, V, n_num, H, Z, B, nb_critic) if len(H) == 2 else None
-    res = dict(value=Bg * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roof,
+    res = dict(value=Bg * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roof, final_losses=final_losses,
                kernel_us_per_iter=breakdown, tagged_kernel_ms_per_iter=tot / nprobe,
                whole_iter_tflops=(flops_iter / (dt / steps) / 1e12) if flops_iter else None,
                whole_iter_mfma_frac=(flops_iter / (dt / steps) / 1e12 / MFMA_F32_PEAK_TF) if flops_iter else None)
@@ -261,6 +288,16 @@ def run_corr(world, rank, n_big, G=18154, n_eval=2287):
     once()
     torch.cuda.synchronize()
     t_std, t_xtx = ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3
+    spot = None
+    if world == 1:   # accuracy of what was just timed: a 64 x 64 block of random gene pairs against float64 (utils.py:816-824)
+        idx = torch.randperm(G, device='cuda', generator=g)[:64]
+        sub = x[:, idx].double()
+        sub = (sub - sub.mean(0)) / sub.std(0, unbiased=False)
+        ref = sub.t() @ sub / n_big
+        blk = c[:, :G][idx][:, idx]
+        spot = dict(max_abs_err_64x64_vs_f64=float((blk.double() - ref).abs().max()),
+                    max_abs_diag_minus_1=float((torch.diagonal(c[:, :G]) - 1).abs().max()),
+                    symmetric=bool(torch.equal(blk, blk.t())))
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([t_std, t_xtx], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
@@ -271,7 +308,7 @@ def run_corr(world, rank, n_big, G=18154, n_eval=2287):
                               tflops_sym=sym / t_xtx / 1e12, tflops_full_convention=2.0 * n_big * G * G / t_xtx / 1e12,
                               mfma_frac=sym / t_xtx / 1e12 / MFMA_F32_PEAK_TF,
                               standardize_gbs=12.0 * n_big * G / t_std / 1e9,
-                              tiles=[tb, te, total])
+                              tiles=[tb, te, total], accuracy=spot)
     return out
 
 
@@ -289,14 +326,19 @@ def corr_cpu_baseline(G=18154, n_eval=2287):
 
 
 def measured_traffic(kernel, B):
-    """HBM bytes per launch from rocprofv3 PMC passes committed under profiles/ (None if absent)."""
+    """HBM bytes per launch of the dominant kernel.  NOT measured in this run: read from the rocprofv3 PMC
+    passes (FETCH_SIZE x 2 + WRITE_SIZE per the guide's gfx950 correction, separate --pmc runs) that
+    tools/collect_profiles.sh left in profiles/traffic.json for the committed tree.  (value, source)."""
     p = os.path.join(ROOT, 'profiles', 'traffic.json')
     try:
         with open(p) as f:
             t = json.load(f)
-        return t.get('%s@B%d' % (kernel, B), {}).get('hbm_bytes_per_launch')
+        e = t.get('%s@B%d' % (kernel, B), {})
+        v = e.get('hbm_bytes_per_launch')
+        return v, ('profiles/traffic.json (static: rocprofv3 PMC of %s, not this run)' % e.get('profile', 'an earlier run')
+                   if v is not None else None)
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(workload, B, budget_s=15.0, nb_critic=5):
@@ -344,6 +386,8 @@ def main():
     ap.add_argument('--secondary', dest='secondary', action='store_true', default=None)
     ap.add_argument('--no-secondary', dest='secondary', action='store_false')
     ap.add_argument('--corr-n', type=int, default=100000, help='samples of the big correlation matrix (0 = skip)')
+    ap.add_argument('--no-extra', dest='extra', action='store_false', default=True,
+                    help='skip the E. coli / wide batch-32 throughput entries')
     a = ap.parse_args()
 
     import torch
@@ -374,6 +418,7 @@ def main():
                                % ('GTEx-shaped' if a.workload == 'gtex' else a.workload, G, V, H, Z, a.batch),
                    'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
         'roofline': res['roofline'],
+        'final_losses': res['final_losses'],
         'kernel_us_per_iter': res['kernel_us_per_iter'],
         'whole_iter_tflops': res['whole_iter_tflops'], 'whole_iter_mfma_frac': res['whole_iter_mfma_frac'],
     }
@@ -388,11 +433,25 @@ def main():
                                  'global_batch': 512 * world,
                                  'roofline': s['roofline'], 'kernel_us_per_iter': s['kernel_us_per_iter'],
                                  'whole_iter_tflops': s['whole_iter_tflops'],
-                                 'whole_iter_mfma_frac': s['whole_iter_mfma_frac']}
+                                 'whole_iter_mfma_frac': s['whole_iter_mfma_frac'], 'final_losses': s['final_losses']}
         except Exception as e:                      # never lose the headline line to the secondary workload
             if world > 1:
                 raise                               # ranks must stay in step: a one-rank failure cannot be skipped
             line['secondary'] = {'error': repr(e)[:200]}
+    if world == 1 and a.extra and a.workload == 'gtex' and a.batch == 32:
+        # the other BASELINE.json configurations at batch 32 from the same tree (throughput only; their parity
+        # cases are tests/test_gpu_fullsize.py): configs[0] E. coli (all genes / as shipped) and configs[4] wide
+        extra = {}
+        for wl in ('ecoli', 'ecoli_crp', 'wide'):
+            try:
+                r = run_gpu(wl, 32, max(20, a.steps // 4), max(5, a.warmup // 2), 1, 0, roofline=False)
+                Gx, Vx, nx, Hx, Zx = WORKLOADS[wl]
+                extra[wl] = dict(value=r['value'], unit='samples/s', ms_per_step=r['ms_per_step'], G=Gx, h=Hx, batch=32,
+                                 p_aug=P_AUG.get(wl, 0), final_losses=r['final_losses'],
+                                 whole_iter_tflops=algorithmic_flops_per_iter(Gx, Vx, nx, Hx, Zx, 32) / (r['ms_per_step'] * 1e-3) / 1e12)
+            except Exception as e:
+                extra[wl] = {'error': repr(e)[:200]}
+        line['extra'] = extra
     if a.corr_n > 0:
         try:
             corr = run_corr(world, rank, a.corr_n)

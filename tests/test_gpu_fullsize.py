@@ -201,3 +201,66 @@ def test_full_size_step_gradients(gpu, name):
     wl, want = O.gen_loss_and_grads(t64(p['z']), tl(p['cc']), t64(p['nc']), O.to_torch(p['gp']), O.to_torch(p['dp']))
     assert abs(float(loss) - float(wl)) <= 1e-4 * max(1.0, abs(float(wl)))
     check(gen.get_gradients(), [g.numpy() for g in want], 'generator')
+
+
+def test_wide_zero_slope_nan_appears_where_the_oracle_has_it(gpu):
+    """tf_utils.py:169 takes sqrt(sum grad^2) without an epsilon: a sample whose critic input gradient is
+    exactly zero turns the penalty, the loss and then every weight into NaN - reference behaviour that is
+    reproduced, not repaired.  On the wide shape (G=20000, H=[1024,1024]: the generic,
+    non-tail launch sequence) two iterations on one synthetic batch followed by another batch produce it in
+    the 13th critic step; the captured iteration must stay within 1e-4 of the fp64 oracle up to that step
+    and turn NaN in the same one (found with bench.py's workload; profiles/r02_wide_zero_slope_nan_matches_oracle.txt)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from adversarial_gene_expression_amd import _dev, _lib, tf_utils as T
+    from adversarial_gene_expression_amd._dev import ptr
+    lib = _lib.load()
+    G, V, n_num, H, Z = bench.WORKLOADS['wide']
+    B, nbc = 32, 5
+    gen = T.Generator(G, V, n_num, H, Z, seed=1)
+    disc = T.Critic(G, V, n_num, H, 1, seed=2)
+    nv = len(V)
+
+    def to_oracle(net):
+        ws = net.get_weights()
+        return {'emb': [w.astype(np.float64) for w in ws[:nv]], 'W': [w.astype(np.float64) for w in ws[nv::2]],
+                'b': [w.astype(np.float64) for w in ws[nv + 1::2]]}
+    tg, td = O.to_torch(to_oracle(gen)), O.to_torch(to_oracle(disc))
+    ogo, odo = O.RMSprop(5e-4), O.RMSprop(5e-4)
+    go, do = T.RMSprop(5e-4), T.RMSprop(5e-4)
+    x, cc, nc = bench.synthetic_batch_pool(G, V, n_num, B * 2, seed=100)
+    torch.set_num_threads(16)
+    T.set_seed(1000)
+    got, want = [], []
+    for i in (0, 0, 1):
+        s = slice(i * B, (i + 1) * B)
+        off0 = T._rng.offset
+        zs, als, _ = [], [], None
+        for _ in range(nbc):
+            zs.append(T.random_normal((B, Z)).cpu().numpy())
+            als.append(T.random_uniform((B,)).cpu().numpy().reshape(B, 1))
+        zs.append(T.random_normal((B, Z)).cpu().numpy())
+        T._rng.offset = off0
+        pair = T._pair(gen, disc, B, nbc + 1)
+        g = pair.iteration_graph(gen, disc, go, do, B, nbc, 10.0, T._rng.seed)
+        losses = _dev.zeros((nbc + 1, 4))
+        xb, cb, nb = x[s].contiguous(), cc[s].contiguous(), nc[s].contiguous()
+        _lib.check(lib.agx_cgan_iter_launch(g, _dev.stream(), ptr(xb), xb.stride(0), ptr(cb), ptr(nb), T._rng.offset,
+                                            ptr(losses)), 'agx_cgan_iter_launch')
+        T._rng.offset += int(lib.agx_cgan_iter_rng_draws(g))
+        lg = losses.cpu().numpy()
+        got += [float(lg[k, 2]) for k in range(nbc)] + [float(lg[nbc, 0])]
+        xo, co, no = t64(xb.cpu().numpy()), tl(cb.cpu().numpy()), t64(nb.cpu().numpy())
+        for k in range(nbc):
+            want.append(float(O.train_disc(xo, t64(zs[k]), co, no, tg, td, odo, t64(als[k]))[0]))
+        want.append(float(O.train_gen(t64(zs[-1]), co, no, tg, td, ogo)[0]))
+    got, want = np.array(got), np.array(want)
+    print('gpu   ', got)
+    print('oracle', want)
+    assert np.isnan(want).any(), 'this trajectory no longer reaches a zero slope: pick the sequence again'
+    first = int(np.argmax(np.isnan(want)))
+    assert first == int(np.argmax(np.isnan(got))) and np.isnan(got[first:]).all() and np.isnan(want[first:]).all()
+    scale = max(1.0, np.abs(want[:first]).max())
+    np.testing.assert_allclose(got[:first], want[:first], rtol=0, atol=1e-4 * scale)
+    assert np.isnan(disc.get_weights()[nv]).all()      # the NaN reaches every weight of W_1, as in the reference
