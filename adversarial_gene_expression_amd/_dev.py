@@ -67,9 +67,41 @@ def world():
     return 1, 0
 
 
+_native = {}
+
+
+def native_comm():
+    """libagx's own RCCL communicator (agx_comm_*: collectives queued on the compute stream by the C library,
+    no c10d call per collective), used when AGX_NATIVE_COMM=1; None otherwise.  The 128-byte RCCL id travels
+    over the torch.distributed process group that launched the job."""
+    import os
+    if os.environ.get('AGX_NATIVE_COMM') != '1':
+        return None
+    import ctypes as C
+    import torch.distributed as dist
+    key = (dist.get_world_size(), dist.get_rank())
+    if key not in _native:
+        lib = _lib.load()
+        device()
+        buf = (C.c_char * 128)()
+        if dist.get_rank() == 0:
+            _lib.check(lib.agx_comm_unique_id(buf), 'agx_comm_unique_id')
+        box = [bytes(buf)]
+        dist.broadcast_object_list(box, src=0)
+        comm = C.c_void_p()
+        _lib.check(lib.agx_comm_init(C.create_string_buffer(box[0], 128), key[0], key[1], C.byref(comm)), 'agx_comm_init')
+        _native[key] = comm
+    return _native[key]
+
+
 def allreduce_sum(t):
     """Sum all-reduce of a device tensor (RCCL; via the host under a gloo rehearsal)."""
     import torch.distributed as dist
+    comm = native_comm() if t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous() else None
+    if comm is not None:
+        _lib.check(_lib.load().agx_comm_allreduce_sum(comm, stream(), t.data_ptr(), t.numel(), int(t.dtype == torch.float64)),
+                   'agx_comm_allreduce_sum')
+        return t
     if t.is_cuda and dist.get_backend() == 'gloo':
         h = t.cpu()
         dist.all_reduce(h)
@@ -82,6 +114,11 @@ def allreduce_sum(t):
 def reduce_scatter_sum(out, inp):
     """out = this rank's 1/R slice of the sum of inp over ranks (RCCL reduce-scatter; via the host under gloo)."""
     import torch.distributed as dist
+    comm = native_comm() if inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous() and out.is_contiguous() else None
+    if comm is not None:
+        _lib.check(_lib.load().agx_comm_reduce_scatter_sum(comm, stream(), inp.data_ptr(), out.data_ptr(), out.numel()),
+                   'agx_comm_reduce_scatter_sum')
+        return out
     if inp.is_cuda and dist.get_backend() == 'gloo':
         ho, hi = out.cpu(), inp.cpu()
         dist.reduce_scatter_tensor(ho, hi)
@@ -94,6 +131,11 @@ def reduce_scatter_sum(out, inp):
 def all_gather(out, inp):
     """out = concatenation of every rank's inp (RCCL all-gather; via the host under gloo)."""
     import torch.distributed as dist
+    comm = native_comm() if inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous() and out.is_contiguous() else None
+    if comm is not None:
+        _lib.check(_lib.load().agx_comm_all_gather(comm, stream(), inp.data_ptr(), out.data_ptr(), inp.numel()),
+                   'agx_comm_all_gather')
+        return out
     if inp.is_cuda and dist.get_backend() == 'gloo':
         ho, hi = out.cpu(), inp.cpu()
         dist.all_gather_into_tensor(ho, hi)

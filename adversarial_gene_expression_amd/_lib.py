@@ -206,6 +206,14 @@ SIGNATURES = {
     'agx_cgan_iter_set_lr': (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
     'agx_cgan_iter_eager': (C.c_int, [_vp, _vp, C.POINTER(IterArgs), _vp, _i32, _vp, _vp, _u64, _vp, C.POINTER(_i64)]),
     'agx_cgan_iter_destroy': (C.c_int, [_vp]),
+    'agx_comm_unique_id': (C.c_int, [_vp]),
+    'agx_comm_init': (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    'agx_comm_destroy': (C.c_int, [_vp]),
+    'agx_comm_size': (_i32, [_vp]),
+    'agx_comm_rank': (_i32, [_vp]),
+    'agx_comm_allreduce_sum': (C.c_int, [_vp, _vp, _vp, _i64, _i32]),
+    'agx_comm_reduce_scatter_sum': (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
+    'agx_comm_all_gather': (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
 }
 
 _lib = None

@@ -41,7 +41,7 @@ struct agx_cgan {
   // workspace views
   int Bm = 0, S = 6, G = 0, Dd = 0, Dg = 0, ldx = 0, ldg0 = 0, ncov = 0;
   float *X = nullptr;                       // [3Bm, ldx] stacked critic input (+cov cols): = Xbuf[0] outside a captured iteration
-  float *Xbuf[2] = {nullptr, nullptr};      // two of them: step k+1's fake rows are assembled beside step k's tail
+  float *Xbuf[2] = {nullptr, nullptr};      // two of them: step k's layer-1 product assembles step k+1's rows in the other (chain_input)
   float *A[AGX_MAX_LAYERS + 1] = {};        // critic activations  [3Bm, ldh]
   float *D[AGX_MAX_LAYERS + 1] = {};        // critic deltas       [3Bm, ldh]
   int ldh[AGX_MAX_LAYERS + 1] = {};
@@ -62,13 +62,6 @@ struct agx_cgan {
   int ldsx = 0;
   float *skws = nullptr;                    // split-K scratch
   int64_t skws_floats = 0;
-  float *skws_aux = nullptr;                // split-K scratch of the side branch (small weight gradients)
-  int64_t skws_aux_floats = 0;
-  // side branches: independent tails of a step (hidden-layer weight gradients, the small-gradient
-  // kernel) run beside the big layer-1 product instead of behind it; forked/joined with events,
-  // so a stream capture records them as parallel graph branches
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   int64_t ws_floats_total = 0;
 };
 
@@ -172,16 +165,6 @@ void carve(agx_cgan *h, float *base) {
   }
   h->skws_floats = r64(need);
   h->skws = cv.take(h->skws_floats);
-  int64_t need_aux = 0;
-  for (int bi = 0; bi < 2; ++bi) {
-    const int B = Bs[bi];
-    for (int l = 1; l < c.disc.n_layers - 1; ++l)
-      need_aux = std::max(need_aux, agx_gemm_ws_floats(c.disc.dims[l], c.disc.dims[l + 1], 3 * B));
-    for (int l = 0; l < c.gen.n_layers; ++l)
-      need_aux = std::max(need_aux, agx_gemm_ws_floats(c.gen.dims[l], c.gen.dims[l + 1], B));
-  }
-  h->skws_aux_floats = r64(need_aux);
-  h->skws_aux = cv.take(h->skws_aux_floats);
   h->ws_floats_total = cv.off;
 }
 
@@ -206,7 +189,6 @@ struct Gemm {  // GEMM call builder
   Gemm &mask(const float *m, int ld) { g.mask = m; g.ldmask = ld; return *this; }
   Gemm &rowscale(const float *r) { g.rowscale = r; return *this; }
   Gemm &rowsq(float *q, int ld) { g.rowsq = q; g.rowsq_ld = ld; return *this; }
-  Gemm &aux_ws(agx_cgan *h) { g.ws = h->skws_aux; g.ws_floats = h->skws_aux_floats; return *this; }
   Gemm &interp(int rows, const float *alpha) { g.interp_rows = rows; g.interp_alpha = alpha; return *this; }
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
   Gemm &opt(const agx::FusedOpt *f) { fo = f; return *this; }
@@ -215,47 +197,11 @@ struct Gemm {  // GEMM call builder
   int run_slabs(hipStream_t st, int *splitk) { return agx::gemm_run(st, &g, nullptr, splitk); }
 };
 
-// Batch from which independent tails of a step run on side streams / the next step's rows are
-// assembled beside the current step.  OFF by default: with the fused epilogues and the faster small
-// kernels the plain one-stream sequence measured 170.6 k samples/s at 512 rows against 165.4 k with
-// both on (every cross-queue fork/join costs 5-9 us of idle GPU).  AGX_SIDE_MIN / AGX_DBL_MIN (rows)
-// switch them back on for experiments; AGX_DBL_MIN needs AGX_SIDE_MIN <= it.
-int side_min() {
-  static const int v = getenv("AGX_SIDE_MIN") ? atoi(getenv("AGX_SIDE_MIN")) : 1 << 30;
-  return v;
-}
 // tiny hidden-layer weight gradients inside the small-gradient launch (AGX_NO_TN_FUSE: own GEMM launches)
 bool tn_fuse() {
   static const bool v = getenv("AGX_NO_TN_FUSE") == nullptr;
   return v;
 }
-int dbl_min() {
-  static const int v = getenv("AGX_DBL_MIN") ? atoi(getenv("AGX_DBL_MIN")) : 1 << 30;
-  return v;
-}
-
-int ensure_side_streams(agx_cgan *h) {
-  if (h->ev_fork) return AGX_OK;
-  for (int i = 0; i < 2; ++i) {
-    AGX_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
-    AGX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-  }
-  AGX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  return AGX_OK;
-}
-// side stream i continues from the current point of st
-int fork_to(agx_cgan *h, hipStream_t st, int i) {
-  AGX_HIP(hipEventRecord(h->ev_fork, st));
-  AGX_HIP(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-  return AGX_OK;
-}
-// st waits for everything queued on side stream i
-int join_from(agx_cgan *h, hipStream_t st, int i) {
-  AGX_HIP(hipEventRecord(h->ev_join[i], h->aux[i]));
-  AGX_HIP(hipStreamWaitEvent(st, h->ev_join[i], 0));
-  return AGX_OK;
-}
-
 // generator layer-1 input rows [0, R): [z | num | emb], covariates of source row r % B
 int gen_input(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, const float *num, int R,
               int B) {
@@ -423,18 +369,9 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     }
   }
   }
-  // kernel gradients: one stacked product per layer (K = 3B).  The big layer-1 product stays on
-  // the main stream; the hidden-layer products and the small-gradient kernel run beside it.
-  // (not at small batches: a cross-queue dependency costs more than the few-microsecond kernels it
-  // would overlap - measured 0.89 vs 0.79 ms per iteration at B = 32; event brackets time one
-  // stream, so profiling keeps everything serial too)
-  const bool side = B >= side_min() && !agx_prof_enabled();
-  if (side) {
-    AGX_TRY(ensure_side_streams(h));
-    AGX_TRY(fork_to(h, st, 0));
-    AGX_TRY(fork_to(h, st, 1));
-  }
-  hipStream_t s_hid = side ? h->aux[0] : st, s_small = side ? h->aux[1] : st;
+  // kernel gradients: one stacked product per layer (K = 3B), everything on the one stream (side-stream
+  // branches for the small products were measured and removed: every cross-queue fork/join costs 5-9 us of
+  // idle GPU, 165.4 k against 170.6 k samples/s at 512 rows, 0.89 against 0.79 ms per iteration at 32)
   // With the flat update appended to the layer-1 product (fo->rest_n), that launch must come LAST:
   // it overwrites the covariate rows of W_1 the embedding gradient reads and needs every other
   // gradient of the step complete.
@@ -445,7 +382,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   auto weight_grad = [&](int l) -> int {
     const float *in = l == 0 ? h->X : h->A[l];
     const int ldin = l == 0 ? ldx : h->ldh[l];
-    if (l > 0 && !side && tn_fuse() && agx::tn_job_ok(m.dims[l], m.dims[l + 1], R)) {
+    if (l > 0 && tn_fuse() && agx::tn_job_ok(m.dims[l], m.dims[l + 1], R)) {
       tn.job[tn.n++] = agx::TnJobs::Job{in, h->D[l + 1], h->dg + m.w_off[l], ldin, h->ldh[l + 1], m.ldw[l],
                                         m.dims[l], m.dims[l + 1], R};
       return AGX_OK;
@@ -455,11 +392,9 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID);
     // layer 1 in a captured iteration: rows [0,G) of W_1 (all rows with dw1_last) are updated in the
     // epilogue.  Safe: every reader of those rows (forward, input gradient, second-order product)
-    // precedes this launch in stream order, and the side branches read only the covariate rows
-    // (>= G) and the deltas
+    // precedes this launch in stream order
     if (l == 0) g.opt(fo);
-    if (l > 0 && side) g.aux_ws(h);
-    return g.run(l == 0 ? st : s_hid);
+    return g.run(st);
   };
   for (int l = L - 1; l >= (dw1_last ? 1 : 0); --l) AGX_TRY(weight_grad(l));
   // everything small in one launch: bias gradients (rows 0..2B), Dense(1) gradient, embedding
@@ -481,12 +416,8 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   }
   j.l_losses = losses; j.l_out = h->out; j.l_slopes = h->slopes; j.l_n0 = B; j.l_n1 = B; j.l_ns = B;
   j.l_inv_b = invb; j.l_gp_weight = gp_weight; j.l_fake_sign = 1.f;
-  AGX_TRY(agx::small_grads_run(s_small, &j, agx::LossCopy{nullptr, nullptr, 0}, &tn));
+  AGX_TRY(agx::small_grads_run(st, &j, agx::LossCopy{nullptr, nullptr, 0}, &tn));
   if (dw1_last) AGX_TRY(weight_grad(0));
-  if (side) {
-    AGX_TRY(join_from(h, st, 0));
-    AGX_TRY(join_from(h, st, 1));
-  }
   return AGX_OK;
 }
 
@@ -503,9 +434,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   AGX_TRY(disc_backward_chain(h, st, B));
   AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1])
               .id(AGX_K_DISC_DX).run(st));
-  // generator backward: the delta chain stays on the main stream, every weight gradient (needs
-  // only the delta just computed) runs beside it on a side stream
-  const bool side = B >= side_min() && !agx_prof_enabled();
+  // generator backward: delta chain and weight gradients on the one stream
   agx_small_grads_t j;
   memset(&j, 0, sizeof(j));
   agx::TnJobs tn;
@@ -518,20 +447,18 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     // output layer in a captured iteration: W_out is updated in the epilogue of its gradient product,
     // which must then follow the delta product that still reads W_out (same stream, after it)
     const bool fused = fo && l == Lg;
-    auto weight_grad = [&](hipStream_t s, bool on_side) -> int {
+    auto weight_grad = [&]() -> int {
       Gemm g(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l], gm.dims[l + 1], B);
       g.id(l == Lg ? AGX_K_GEN_DW_OUT : AGX_K_GEN_DW_HID);
-      if (on_side) g.aux_ws(h);
       if (fused) g.opt(fo);
-      return g.run(s);
+      return g.run(st);
     };
-    if (!fused && !side && tn_fuse() && agx::tn_job_ok(gm.dims[l], gm.dims[l + 1], B)) {
+    if (!fused && tn_fuse() && agx::tn_job_ok(gm.dims[l], gm.dims[l + 1], B)) {
       // a few 32x32 tiles over K = B rows: rides the small-gradient launch at the end of the step
       tn.job[tn.n++] = agx::TnJobs::Job{in, dout, h->gg + gm.w_off[l], ldin, lddout, gm.ldw[l], gm.dims[l],
                                         gm.dims[l + 1], B};
     } else if (!fused) {
-      if (side) AGX_TRY(fork_to(h, st, 0));
-      AGX_TRY(weight_grad(side ? h->aux[0] : st, side));
+      AGX_TRY(weight_grad());
     }
     j.cs_A[j.n_colsum] = dout; j.cs_lda[j.n_colsum] = lddout; j.cs_r0[j.n_colsum] = 0; j.cs_r1[j.n_colsum] = B;
     j.cs_H[j.n_colsum] = gm.dims[l + 1]; j.cs_out[j.n_colsum] = h->gg + gm.b_off[l];
@@ -542,7 +469,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
       g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
       AGX_TRY(g.run(st));
     }
-    if (fused && !(fo->rest_n > 0)) AGX_TRY(weight_grad(st, false));
+    if (fused && !(fo->rest_n > 0)) AGX_TRY(weight_grad());
     if (l > 0) {
       dout = h->gd[l];
       lddout = h->ldgh[l];
@@ -556,7 +483,6 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   j.l_losses = losses; j.l_out = h->out; j.l_n0 = B; j.l_n1 = 0; j.l_ns = 0;   // mean(-D(fake))  :253
   j.l_inv_b = invb; j.l_gp_weight = 0.f; j.l_fake_sign = 1.f;
   AGX_TRY(agx::small_grads_run(st, &j, lc ? *lc : agx::LossCopy{nullptr, nullptr, 0}, &tn));
-  if (side) AGX_TRY(join_from(h, st, 0));
   if (fo && fo->rest_n > 0) {
     // output-layer product LAST: its launch also runs the flat update of every other generator
     // parameter, whose gradients the launches above have completed
@@ -616,13 +542,6 @@ extern "C" int agx_cgan_create(const agx_cgan_config_t *cfg, agx_cgan_t **out) {
 }
 
 extern "C" int agx_cgan_destroy(agx_cgan_t *h) {
-  if (h) {
-    for (int i = 0; i < 2; ++i) {
-      if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
-      if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  }
   delete h;
   return AGX_OK;
 }
@@ -645,7 +564,6 @@ extern "C" int agx_cgan_bind(agx_cgan_t *h, float *gen_params, float *gen_grads,
   }
   h->gp = gen_params; h->gg = gen_grads; h->dp = disc_params; h->dg = disc_grads;
   carve(h, static_cast<float *>(workspace));
-  AGX_TRY(ensure_side_streams(h));   // here, never inside a stream capture
   h->bound = true;
   return AGX_OK;
 }
@@ -731,7 +649,7 @@ bool chain_input(const agx_cgan *h, const agx_iter_args_t *a) {
   static const bool off = getenv("AGX_NO_CHAIN_INPUT") != nullptr;
   const agx_mlp_desc_t &dm = h->cfg.disc;
   if (off || a->split || a->opt_kind != 0 || a->nb_critic < 1 || a->aug_mask_disc || a->aug_mask_gen) return false;
-  if (a->B >= dbl_min() || a->B >= side_min() || getenv("AGX_NO_FUSED_OPT") || getenv("AGX_NO_FUSED_REST")) return false;
+  if (getenv("AGX_NO_FUSED_OPT") || getenv("AGX_NO_FUSED_REST")) return false;
   if (h->ldsx % 4 != 0 || h->ldx % 4 != 0) return false;
   int64_t emb_end = 0;
   for (int i = 0; i < dm.emb.n_cat; ++i)
@@ -761,20 +679,19 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const int64_t ghole_lo = gm0.w_off[Lg0], ghole_hi = gm0.w_off[Lg0] + (int64_t)gm0.dims[Lg0] * gm0.ldw[Lg0];
   const bool adam = a->opt_kind == 1;
   const bool fuse = seg < 0 && !a->split && B < 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
-  // from 128 rows on the critic's product always fuses (+0.7 % at 512 rows); the generator's only while
-  // its weight gradients are not on a side stream (AGX_SIDE_MIN), or AGX_FUSE_GEN_BIG=0
+  // from 128 rows on the critic's product always fuses (+0.7 % at 512 rows); the generator's unless AGX_FUSE_GEN_BIG=0
   const bool fuse_big = seg < 0 && !a->split && B >= 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
   static const bool gen_big = !(getenv("AGX_FUSE_GEN_BIG") && atoi(getenv("AGX_FUSE_GEN_BIG")) == 0);
-  const bool fuse_gbig = fuse_big && gen_big && B < side_min();
+  const bool fuse_gbig = fuse_big && gen_big;
   const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], 3 * B, h->skws_floats);
   const bool fuse_g = (fuse || fuse_gbig) && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], B, h->skws_floats);
   agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
   agx::FusedOpt gfo{h->gp + ghole_lo, a->gen_rms + ghole_lo, gm0.dims[Lg0], a->lr_gen, a->rho, a->eps};
-  // ... and (one stream, no side branches) the same launch updates the rest of the flat buffer:
+  // ... and the same launch updates the rest of the flat buffer:
   // the critic's product then takes ALL rows of W_1, and no optimizer launch is left in the step
-  const bool rest = B < side_min() && !getenv("AGX_NO_FUSED_REST");
+  const bool rest = !getenv("AGX_NO_FUSED_REST");
   const int64_t dfull_hi = dm.w_off[0] + (int64_t)dm.dims[0] * dm.ldw[0];
   const bool rest_d = rest && dfull_hi % 4 == 0 && dfull_hi <= (dm.n_flat & ~(int64_t)3);
   if (rest_d) {
@@ -829,12 +746,10 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     AGX_TRY(flush());
   }
   *draws = (int64_t)sub;
-  // Large batches use two stacked-input buffers alternately: while step k works on one, a side
-  // stream assembles step k+1's fake rows (a 2*B*G*4-byte copy) in the other, beside step k's kernels.
-  const bool dbl = B >= dbl_min() && !agx_prof_enabled();
-  // chained input assembly (see chain_input): needs the critic product to carry the flat update
-  const bool chainx = seg < 0 && fuse_d && rest_d && !dbl && chain_input(h, a);
-  float *Xb[2] = {h->Xbuf[0], (dbl || chainx) ? h->Xbuf[1] : h->Xbuf[0]};
+  // chained input assembly (see chain_input): needs the critic product to carry the flat update; steps then
+  // alternate between the two stacked-input buffers
+  const bool chainx = seg < 0 && fuse_d && rest_d && chain_input(h, a);
+  float *Xb[2] = {h->Xbuf[0], chainx ? h->Xbuf[1] : h->Xbuf[0]};
   struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; } } restore{h};
   // fake rows of step k (k == nbc: the generator step's rows [0,B)) into buffer k&1; with_cov: also
   // the covariate columns of the step's rows from the CURRENT embedding tables (same launch)
@@ -854,21 +769,12 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     // real rows were staged into buffer 0 rows [0,B) (agx_cgan_iter_stage) and stay there for all
     // critic steps (augmentation noise is a trace constant, :210); buffer 1 gets a copy
     if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, Xb[0], h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
-    if (dbl && nbc > 1)
-      AGX_HIP(hipMemcpy2DAsync(Xb[1], (size_t)h->ldx * 4, Xb[0], (size_t)h->ldx * 4, (size_t)G * 4, B,
-                               hipMemcpyDeviceToDevice, st));
-    if (dbl) AGX_TRY(place_fake(0, st));
   }
   for (int k = 0; k < nbc; ++k) {
     h->X = Xb[k & 1];
     if (in_seg(k)) {
       // covariate columns of [real; fake] from the CURRENT (just updated) embedding tables
-      if (dbl) AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, 2 * B, B));
-      else if (!chainx || k == 0) AGX_TRY(place_fake(k, st, true));
-      if (dbl) {   // next step's rows on a side stream; critic_core's own fork/join of aux[1] joins it
-        AGX_TRY(fork_to(h, st, 1));
-        AGX_TRY(place_fake(k + 1, h->aux[1]));
-      }
+      if (!chainx || k == 0) AGX_TRY(place_fake(k, st, true));
       agx::FusedOpt dk = dfo;
       if (chainx) {   // step k+1's rows (the generator step's rows [0,B) when k+1 == nbc) into the other buffer
         const bool gnext = (k + 1 == nbc);
@@ -892,9 +798,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   }
   h->X = Xb[nbc & 1];
   if (in_seg(nbc)) {
-    if (chainx) {}   // assembled by the last critic step's layer-1 product
-    else if (!dbl || nbc == 0) AGX_TRY(place_fake(nbc, st, true));
-    else AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));
+    if (!chainx) AGX_TRY(place_fake(nbc, st, true));   // else: assembled by the last critic step's layer-1 product
     AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc,
                      fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));
   }

@@ -419,12 +419,34 @@ int64_t agx_cgan_iter_rng_draws(const agx_iter_graph_t *g);
 int agx_cgan_iter_set_lr(agx_iter_graph_t *g, const float *lr_t_host, int32_t n);
 /* The same launch sequence as the captured one-GPU iteration (fused epilogues included), queued
  * directly on `stream` instead of replayed: what agx_prof_* brackets (events cannot be captured) and
- * debuggers see.  With profiling enabled the side-stream branches run in line.  *draws_out (host,
+ * debuggers see.  *draws_out (host,
  * optional) receives the number of RNG stream positions consumed. */
 int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_args_t *a, const float *x,
                         int32_t ldx, const int32_t *cat, const float *num, uint64_t rng_offset,
                         float *losses_out, int64_t *draws_out);
 int agx_cgan_iter_destroy(agx_iter_graph_t *g);
+
+/* ---- RCCL over xGMI for hosts without PyTorch (no reference counterpart: the reference ----
+ *      is one process on one GPU, tf_utils.py:17-38).  One process per GPU; librccl is bound with
+ *      dlopen at the first call (the copy already in the process, e.g. PyTorch's, is reused).
+ *      Rank 0 calls agx_comm_unique_id and hands the 128 bytes to the other ranks by any host
+ *      channel; every rank then calls agx_comm_init with the current HIP device selected.  The
+ *      collectives are queued on `stream` like every other entry point (no host synchronisation):
+ *        data-parallel step:   agx_cgan_disc_grads -> agx_comm_reduce_scatter_sum(flat gradients)
+ *                              -> agx_opt_rmsprop on the own 1/R shard -> agx_comm_all_gather(parameters)
+ *        tiled Gamma:          agx_gamma_sums_tiles on the own tiles -> agx_comm_allreduce_sum(6 doubles) */
+typedef struct agx_comm agx_comm_t;
+int agx_comm_unique_id(void *id128_host);
+int agx_comm_init(const void *id128_host, int32_t nranks, int32_t rank, agx_comm_t **out);
+int agx_comm_destroy(agx_comm_t *c);
+int32_t agx_comm_size(const agx_comm_t *c);
+int32_t agx_comm_rank(const agx_comm_t *c);
+/* in place sum over ranks of n fp32 (f64 = 0) or fp64 (f64 = 1) values */
+int agx_comm_allreduce_sum(agx_comm_t *c, void *stream, void *buf, int64_t n, int32_t f64);
+/* out[0..n_per_rank) = sum over ranks of in[rank*n_per_rank ..]; in holds nranks*n_per_rank floats */
+int agx_comm_reduce_scatter_sum(agx_comm_t *c, void *stream, const float *in, float *out, int64_t n_per_rank);
+/* out[r*n_per_rank ..] = rank r's in[0..n_per_rank) */
+int agx_comm_all_gather(agx_comm_t *c, void *stream, const float *in, float *out, int64_t n_per_rank);
 
 #ifdef __cplusplus
 }

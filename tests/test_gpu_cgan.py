@@ -395,9 +395,9 @@ def test_data_parallel_shards_reproduce_the_big_batch(gpu, cuts):
 
 @pytest.mark.parametrize('p_aug', [0, 0.25])
 def test_large_batch_graph_paths_match_eager(gpu, p_aug):
-    """Batches >= 128 take the side-branch / double-buffered form of the captured iteration (fake rows
-    of step k+1 assembled beside step k, weight gradients on side streams): same results as the
-    eager step functions.  Ragged tail of 72 rows (< 128) switches back to the serial form."""
+    """Batches >= 128 take the large-batch form of the captured iteration (RMSprop fused into the big
+    weight-gradient products through the LDS-tiled kernels, K = 3B >= 384): same results as the eager
+    step functions.  The ragged tail of 72 rows (< 128) takes the small-batch form."""
     from adversarial_gene_expression_amd import tf_utils as T
     p = make_problem(G=150, B=200, H=(32, 24), seed=71)
     x32 = p['x'].astype(np.float32)

@@ -229,7 +229,7 @@ def test_wide_zero_slope_nan_appears_where_the_oracle_has_it(gpu):
     tg, td = O.to_torch(to_oracle(gen)), O.to_torch(to_oracle(disc))
     ogo, odo = O.RMSprop(5e-4), O.RMSprop(5e-4)
     go, do = T.RMSprop(5e-4), T.RMSprop(5e-4)
-    x, cc, nc = bench.synthetic_batch_pool(G, V, n_num, B * 2, seed=100)
+    x, cc, nc = bench.synthetic_batch_pool(G, V, n_num, B * 8, seed=100)      # the pool bench.py draws (8 batches)
     torch.set_num_threads(16)
     T.set_seed(1000)
     got, want = [], []

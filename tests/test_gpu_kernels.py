@@ -351,3 +351,36 @@ def test_empty_bracket_overhead_is_small_and_positive(gpu):
     _lib.check(lib.agx_prof_empty_bracket_us(_dev.stream(), 64, ctypes.byref(us)))
     assert 0.0 <= us.value < 50.0
     assert lib.agx_prof_empty_bracket_us(_dev.stream(), 0, ctypes.byref(us)) != 0   # n out of range
+
+
+def test_rccl_communicator_of_one_rank(gpu):
+    """agx_comm_* (RCCL bound with dlopen) on the one GPU of the box: a communicator of one rank, whose
+    collectives are the identity, queued on the compute stream between kernels of the library.  More ranks
+    need more GPUs (RCCL refuses two ranks on one device): the multi-rank algebra is covered by the gloo tests."""
+    import ctypes as C
+    import torch
+    from adversarial_gene_expression_amd import _dev, _lib
+    lib = _lib.load()
+    ident = (C.c_char * 128)()
+    _lib.check(lib.agx_comm_unique_id(ident), 'agx_comm_unique_id')
+    comm = C.c_void_p()
+    _lib.check(lib.agx_comm_init(ident, 1, 0, C.byref(comm)), 'agx_comm_init')
+    try:
+        assert lib.agx_comm_size(comm) == 1 and lib.agx_comm_rank(comm) == 0
+        st = _dev.stream()
+        x = torch.randn(4099, device='cuda')
+        ref = x.clone()
+        _lib.check(lib.agx_comm_allreduce_sum(comm, st, x.data_ptr(), x.numel(), 0), 'agx_comm_allreduce_sum')
+        d = torch.randn(6, device='cuda', dtype=torch.float64)
+        dref = d.clone()
+        _lib.check(lib.agx_comm_allreduce_sum(comm, st, d.data_ptr(), 6, 1), 'agx_comm_allreduce_sum')
+        out = torch.zeros(4096, device='cuda')
+        _lib.check(lib.agx_comm_reduce_scatter_sum(comm, st, x.data_ptr(), out.data_ptr(), 4096), 'agx_comm_reduce_scatter_sum')
+        gathered = torch.zeros(4096, device='cuda')
+        _lib.check(lib.agx_comm_all_gather(comm, st, out.data_ptr(), gathered.data_ptr(), 4096), 'agx_comm_all_gather')
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref) and torch.equal(d, dref)
+        assert torch.equal(out, ref[:4096]) and torch.equal(gathered, ref[:4096])
+        assert lib.agx_comm_allreduce_sum(None, st, x.data_ptr(), 4, 0) == -1
+    finally:
+        lib.agx_comm_destroy(comm)
