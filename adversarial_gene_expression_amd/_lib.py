@@ -44,6 +44,8 @@ class GemmDesc(C.Structure):
         ('prof_tagged', C.c_int32),
         ('interp_rows', C.c_int32),
         ('interp_alpha', C.c_void_p),
+        ('col_scale', C.c_void_p),
+        ('col_shift', C.c_void_p),
     ]
 
 
@@ -154,6 +156,8 @@ SIGNATURES = {
     'agx_sizeof': (_i64, [_i32]),
     'agx_gemm_f32': (C.c_int, [_vp, C.POINTER(GemmDesc)]),
     'agx_gemm_ws_floats': (_i64, [_i32, _i32, _i32]),
+    'agx_bn_fold': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _i32]),
+    'agx_affine_act': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _f32]),
     'agx_embed_concat_fwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32,
                                        _vp, _i32, _i32, _i32, _vp, _i32]),
     'agx_embed_bwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32]),

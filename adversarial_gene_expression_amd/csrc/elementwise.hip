@@ -1287,3 +1287,53 @@ int agx::iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2,
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
+
+
+// ---- optional batch-norm stage (no reference counterpart: tf_utils.py:85-88 has Dense + ReLU only) ----
+namespace {
+__global__ void __launch_bounds__(256) bn_fold_kernel(const float *__restrict__ mean, const float *__restrict__ vs,
+                                                      int is_std, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float eps,
+                                                      float *__restrict__ scale, float *__restrict__ shift, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float var = is_std ? vs[n] * vs[n] : vs[n];
+  const float sc = (gamma ? gamma[n] : 1.f) / sqrtf(var + eps);
+  scale[n] = sc;
+  shift[n] = (beta ? beta[n] : 0.f) - mean[n] * sc;
+}
+
+__global__ void __launch_bounds__(256) affine_act_kernel(float *__restrict__ y, int ldy, int M, int N,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int act, float slope) {
+  const int r = blockIdx.y;
+  float *row = y + (size_t)r * ldy;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += gridDim.x * blockDim.x) {
+    float v = row[c] * scale[c] + shift[c];
+    if (act) v = v > 0.f ? v : v * slope;
+    row[c] = v;
+  }
+}
+}  // namespace
+
+extern "C" int agx_bn_fold(void *stream, const float *mean, const float *var_or_std, int32_t is_std,
+                           const float *gamma, const float *beta, float eps, float *scale, float *shift, int32_t N) {
+  AGX_CHECK_ARG(mean && var_or_std && scale && shift && N > 0 && eps >= 0.f, "agx_bn_fold: bad argument");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(agx::cdiv(N, 256)), dim3(256), 0, agx::as_stream(stream), mean, var_or_std,
+                     is_std, gamma, beta, eps, scale, shift, N);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_affine_act(void *stream, float *y, int32_t ldy, int32_t M, int32_t N, const float *scale,
+                              const float *shift, int32_t act, float slope) {
+  AGX_CHECK_ARG(y && scale && shift && M >= 0 && N > 0 && ldy >= N, "agx_affine_act: bad argument");
+  hipStream_t st = agx::as_stream(stream);
+  for (int r0 = 0; r0 < M; r0 += 65535) {
+    const int rows = std::min(65535, M - r0);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(std::min(agx::cdiv(N, 256), 64), rows), dim3(256), 0, st,
+                       y + (size_t)r0 * ldy, ldy, rows, N, scale, shift, act, slope);
+    AGX_LAUNCH_CHECK();
+  }
+  return AGX_OK;
+}

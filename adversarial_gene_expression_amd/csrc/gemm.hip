@@ -41,6 +41,8 @@ struct KParams {
   int ldmask;
   int accumulate;
   const float *rowscale;  // v *= rowscale[row] (before bias)
+  const float *col_scale, *col_shift;  // optional per-feature affine stage after the bias: v = v*scale[col] + shift[col]
+                                       // (batch-norm with folded statistics; NULL on the reference path: no BN, tf_utils.py:85-88)
   float *rowsq;           // [M, rowsq_ld]: per 32-column slab sum of squares of the stored values
   int rowsq_ld;
   float *ws;
@@ -188,6 +190,7 @@ __device__ __forceinline__ float epilogue_store(const KParams &p, int row, int c
   if (p.rowscale) v *= p.rowscale[row];
   if (p.bias) v += p.bias[col];
   if (p.addrow) v += p.addrow[(size_t)(row % p.addmod) * p.ldadd + col];
+  if (p.col_scale) v = v * p.col_scale[col] + p.col_shift[col];
   if (p.act) v = v > 0.f ? v : v * p.slope;
   if (p.mask) {
     float mk = p.mask[(size_t)row * p.ldmask + col];
@@ -207,11 +210,15 @@ __device__ __forceinline__ void epilogue_column(const KParams &p, const int (&ro
                                                 float (&v)[NV]) {
   const int cc = min(col, p.N - 1);
   const bool colok = col < p.N;
-  float bias = 0.f, add[NV], mk[NV], old[NV], rs[NV];
+  float bias = 0.f, csc = 1.f, csh = 0.f, add[NV], mk[NV], old[NV], rs[NV];
   int cr[NV];
 #pragma unroll
   for (int e = 0; e < NV; ++e) cr[e] = min(rows[e], p.M - 1);
   if (p.bias) bias = p.bias[cc];
+  if (p.col_scale) {
+    csc = p.col_scale[cc];
+    csh = p.col_shift[cc];
+  }
   if (p.rowscale) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) rs[e] = p.rowscale[cr[e]];
@@ -258,6 +265,7 @@ __device__ __forceinline__ void epilogue_column(const KParams &p, const int (&ro
     if (p.rowscale) x *= rs[e];
     if (p.bias) x += bias;
     if (p.addrow) x += add[e];
+    if (p.col_scale) x = x * csc + csh;
     if (p.act) x = x > 0.f ? x : x * p.slope;
     if (p.mask) x = mk[e] > 0.f ? x : x * p.slope;
     if (p.accumulate) x += old[e];
@@ -713,7 +721,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
         } else if (OPT) {
           epilogue_column<16, true>(p, rows, col, v);
         } else if (OPTI && m0 + BM <= p.M && n0 + BN <= p.N && !p.rowscale && !p.addrow && !p.mask &&
-                   !p.accumulate && !p.rowsq) {
+                   !p.accumulate && !p.rowsq && !p.col_scale) {
           // interior tile of a plain Dense product (alpha, bias, activation): one base pointer, no clamps
           const float bias = p.bias ? p.bias[col] : 0.f;
           float *__restrict__ cb = p.C + (size_t)rbase * p.ldc + col;
@@ -1346,6 +1354,8 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   p.act = g->act; p.slope = g->slope; p.mask = g->mask; p.ldmask = g->ldmask;
   p.accumulate = g->accumulate;
   p.rowscale = g->rowscale;
+  AGX_CHECK_ARG((g->col_scale == nullptr) == (g->col_shift == nullptr), "agx_gemm_f32: col_scale and col_shift go together");
+  p.col_scale = g->col_scale; p.col_shift = g->col_shift;
   p.rowsq = g->rowsq;
   p.rowsq_ld = g->rowsq_ld;
   p.ws = g->ws;
@@ -1354,7 +1364,7 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   const bool opt = fo && fo->rows > 0;
   if (opt) {
     AGX_CHECK_ARG(fo->w && fo->s1 && g->ta && !g->tb && !g->rowsq && g->interp_rows == 0 && !g->bias && !g->addrow &&
-                      !g->act && !g->mask && !g->accumulate && !g->rowscale,
+                      !g->act && !g->mask && !g->accumulate && !g->rowscale && !g->col_scale,
                   "agx_gemm_f32: the fused optimizer takes a plain TN weight-gradient product");
     p.opt_w = fo->w; p.opt_s1 = fo->s1;
     p.opt_rows = fo->rows < g->M ? fo->rows : g->M;

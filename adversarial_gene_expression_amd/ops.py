@@ -12,7 +12,7 @@ from ._dev import ptr
 
 def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0, slope=0.0, mask=None,
          out=None, accumulate=False, rowscale=None, rowsq=None, force_cfg=-1, force_splitk=0, use_ws=True,
-         interp=None):
+         interp=None, col_scale=None, col_shift=None):
     """out[M, N] = epilogue(alpha * op(A) @ op(B)); leading dimensions are the row strides."""
     lib = _lib.load()
     if out is None:
@@ -31,6 +31,7 @@ def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0,
         g.mask, g.ldmask = ptr(mask), mask.stride(0)
     g.accumulate = int(accumulate)
     g.rowscale = ptr(rowscale)
+    g.col_scale, g.col_shift = ptr(col_scale), ptr(col_shift)
     if rowsq is not None:
         g.rowsq, g.rowsq_ld = ptr(rowsq), rowsq.stride(0)
     ws = None
@@ -44,6 +45,32 @@ def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0,
         g.interp_rows, g.interp_alpha = interp[0], ptr(interp[1])
     _lib.check(lib.agx_gemm_f32(_dev.stream(), g), 'agx_gemm_f32')
     return out
+
+
+def dense_bn(x, W, b, M, N, K, *, gamma=None, beta=None, eps=1e-3, slope=0.0, act=1, running=None):
+    """Dense + batch-norm + (leaky-)ReLU, the optional stage BASELINE.json's north_star names (the reference has
+    no batch-norm, tf_utils.py:85-88: nothing on the parity path calls this).
+    running=(mean, var): inference form - statistics folded into a per-feature scale / shift applied in the
+    GEMM epilogue, ONE launch.  running=None: batch statistics (biased variance over the M rows, as Keras
+    BatchNormalization in training mode): GEMM with bias -> column statistics -> folded affine + activation in
+    place.  Returns (y, mean, var) with the statistics used."""
+    lib = _lib.load()
+    scale, shift = _dev.empty(N), _dev.empty(N)
+    if running is not None:
+        mean, var = running
+        _lib.check(lib.agx_bn_fold(_dev.stream(), ptr(mean), ptr(var), 0, ptr(gamma), ptr(beta), eps, ptr(scale),
+                                   ptr(shift), N), 'agx_bn_fold')
+        return gemm(x, W, M, N, K, bias=b, act=act, slope=slope, col_scale=scale, col_shift=shift), mean, var
+    y = gemm(x, W, M, N, K, bias=b)
+    mean, std = _dev.empty(N), _dev.empty(N)
+    nws = int(lib.agx_colstats_ws_doubles(M, N))
+    ws = _dev.empty(nws, dtype=torch.float64)
+    _lib.check(lib.agx_colstats(_dev.stream(), ptr(y), y.stride(0), M, N, ptr(mean), ptr(std), ptr(ws), nws), 'agx_colstats')
+    _lib.check(lib.agx_bn_fold(_dev.stream(), ptr(mean), ptr(std), 1, ptr(gamma), ptr(beta), eps, ptr(scale), ptr(shift), N),
+               'agx_bn_fold')
+    _lib.check(lib.agx_affine_act(_dev.stream(), ptr(y), y.stride(0), M, N, ptr(scale), ptr(shift), act, slope),
+               'agx_affine_act')
+    return y, mean, std * std
 
 
 def colsum(A, r0, r1, H, out=None, accumulate=False):

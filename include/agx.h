@@ -109,10 +109,27 @@ typedef struct agx_gemm {
   const float *interp_alpha; /* [0,2R) as usual and C[2R+b] = epilogue(r_b + alpha[b]*(f_b - r_b)):  */
                         /* the Dense layer applied to real + alpha*(fake-real) (tf_utils.py:162-167) */
                         /* by linearity, without a third pass over B.  Needs ws >= M*N floats. */
+  const float *col_scale; /* [N] or NULL (then col_shift NULL too): optional per-feature affine stage    */
+  const float *col_shift; /* after the bias, before the activation: v = v*col_scale[n] + col_shift[n] -    */
+                        /* batch normalisation with folded statistics (agx_bn_fold).  The reference has */
+                        /* no batch-norm (tf_utils.py:85-88): NULL on the parity path.                  */
 } agx_gemm_t;
 int agx_gemm_f32(void *stream, const agx_gemm_t *p);
 /* Upper bound on the split-K scratch (floats) the heuristic may ask for. */
 int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K);
+
+/* Optional batch-norm stage of a Dense layer (BASELINE.json north_star; the reference itself has none,
+ * tf_utils.py:85-88, so nothing on the parity path calls these).
+ *   inference / folded:  scale = gamma / sqrt(var + eps), shift = beta - mean * scale  (agx_bn_fold), then
+ *                        ONE launch: agx_gemm_f32 with bias, col_scale / col_shift and the activation;
+ *   batch statistics:    agx_gemm_f32 (bias only) -> agx_colstats over the batch rows (mean, population
+ *                        std) -> agx_bn_fold(var = std^2) -> agx_affine_act in place.
+ * var_or_std: is_std = 0 -> variances, 1 -> standard deviations (what agx_colstats returns).        */
+int agx_bn_fold(void *stream, const float *mean, const float *var_or_std, int32_t is_std, const float *gamma,
+                const float *beta, float eps, float *scale, float *shift, int32_t N);
+/* y[m,n] = act(y[m,n]*scale[n] + shift[n]) in place; act: leaky-ReLU with `slope` (0 = ReLU), act = 0: none */
+int agx_affine_act(void *stream, float *y, int32_t ldy, int32_t M, int32_t N, const float *scale,
+                   const float *shift, int32_t act, float slope);
 
 /* ---- embeddings: tf_utils.py:64-76, 120-131 ---------------------------- */
 typedef struct agx_embed {
