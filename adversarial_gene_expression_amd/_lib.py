@@ -193,6 +193,11 @@ SIGNATURES = {
     'agx_pearson_sums': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'agx_gamma_sums': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'agx_gamma_sums_tiles': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
+    'agx_colstats_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64]),
+    'agx_standardize_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
+    'agx_corr_xty_f64': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, C.c_double, _vp, _i32]),
+    'agx_pearson_sums_f64': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    'agx_gamma_sums_f64': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     'agx_cgan_create': (C.c_int, [C.POINTER(CganConfig), C.POINTER(_vp)]),
     'agx_cgan_destroy': (C.c_int, [_vp]),
     'agx_cgan_workspace_bytes': (_i64, [_vp]),

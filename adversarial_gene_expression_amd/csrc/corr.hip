@@ -18,7 +18,8 @@ using agx::wave_sum;
 // ws[chunk][2][G], shift = the column's first row (sums about a value inside the data keep the
 // variance well conditioned when |mean| >> std: raw log-expression values).  Stage 2 adds the chunks
 // in index order.
-__global__ void __launch_bounds__(256) colstats_partial_kernel(const float *__restrict__ x, int ldx,
+template <typename T>
+__global__ void __launch_bounds__(256) colstats_partial_kernel(const T *__restrict__ x, int ldx,
                                                                int N, int G, int rows_per_chunk,
                                                                double *__restrict__ ws) {
   __shared__ double red[2][4][64];
@@ -47,10 +48,11 @@ __global__ void __launch_bounds__(256) colstats_partial_kernel(const float *__re
   }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) colstats_finish_kernel(const double *__restrict__ ws, int chunks,
-                                                              const float *__restrict__ x, int N, int G,
-                                                              float *__restrict__ mean,
-                                                              float *__restrict__ stdv) {
+                                                              const T *__restrict__ x, int N, int G,
+                                                              T *__restrict__ mean,
+                                                              T *__restrict__ stdv) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= G) return;
   double s = 0.0, q = 0.0;
@@ -61,17 +63,18 @@ __global__ void __launch_bounds__(256) colstats_finish_kernel(const double *__re
   const double d = s / (double)N;          // mean - shift
   double var = q / (double)N - d * d;
   if (var < 0.0) var = 0.0;
-  mean[c] = (float)((double)x[c] + d);
-  stdv[c] = (float)sqrt(var);
+  mean[c] = (T)((double)x[c] + d);
+  stdv[c] = (T)sqrt(var);
 }
 
-__global__ void __launch_bounds__(256) standardize_kernel(const float *__restrict__ x, int ldx,
-                                                          int G, const float *__restrict__ mean,
-                                                          const float *__restrict__ stdv,
-                                                          float *__restrict__ out, int ldo) {
+template <typename T>
+__global__ void __launch_bounds__(256) standardize_kernel(const T *__restrict__ x, int ldx,
+                                                          int G, const T *__restrict__ mean,
+                                                          const T *__restrict__ stdv,
+                                                          T *__restrict__ out, int ldo) {
   const int r = blockIdx.y;
-  const float *xr = x + (size_t)r * ldx;
-  float *orow = out + (size_t)r * ldo;
+  const T *xr = x + (size_t)r * ldx;
+  T *orow = out + (size_t)r * ldo;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < G; c += gridDim.x * blockDim.x)
     orow[c] = (xr[c] - mean[c]) / stdv[c];  // x/0 -> inf/NaN exactly as NumPy
 }
@@ -191,17 +194,18 @@ __global__ void __launch_bounds__(256) sums_finish_kernel(const double *__restri
   }
 }
 
-__global__ void __launch_bounds__(256) pearson_sums_kernel(const float *__restrict__ a,
-                                                           const float *__restrict__ b, long long n,
+template <typename T>
+__global__ void __launch_bounds__(256) pearson_sums_kernel(const T *__restrict__ a,
+                                                           const T *__restrict__ b, long long n,
                                                            int one_minus,
                                                            double *__restrict__ part) {
   double s[6] = {0, 0, 0, 0, 0, 0};
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    float fa = a[i], fb = b[i];
+    T fa = a[i], fb = b[i];
     if (one_minus) {
-      fa = 1.0f - fa;  // utils.py:870-871 (fp32 subtraction)
-      fb = 1.0f - fb;
+      fa = (T)1 - fa;  // utils.py:870-871 (subtraction in the input's own precision)
+      fb = (T)1 - fb;
     }
     const double da = fa, db = fb;
     s[0] += da; s[1] += db; s[2] += da * da; s[3] += db * db; s[4] += da * db;
@@ -209,15 +213,16 @@ __global__ void __launch_bounds__(256) pearson_sums_kernel(const float *__restri
   block_add5(s, 5, part);
 }
 
-__global__ void __launch_bounds__(256) gamma_sums_kernel(const float *__restrict__ C1, int ld1,
-                                                         const float *__restrict__ C2, int ld2,
+template <typename T>
+__global__ void __launch_bounds__(256) gamma_sums_kernel(const T *__restrict__ C1, int ld1,
+                                                         const T *__restrict__ C2, int ld2,
                                                          int G, double *__restrict__ part) {
   double s[6] = {0, 0, 0, 0, 0, 0};
   for (int i = blockIdx.x; i < G; i += gridDim.x) {
-    const float *r1 = C1 + (size_t)i * ld1;
-    const float *r2 = C2 + (size_t)i * ld2;
+    const T *r1 = C1 + (size_t)i * ld1;
+    const T *r2 = C2 + (size_t)i * ld2;
     for (int j = i + 1 + threadIdx.x; j < G; j += blockDim.x) {
-      const float fa = 1.0f - r1[j], fb = 1.0f - r2[j];
+      const T fa = (T)1 - r1[j], fb = (T)1 - r2[j];
       if (isnan(fa) || isnan(fb)) {
         s[5] += 1.0;
       } else {
@@ -290,14 +295,15 @@ int colstats_chunks(int N, int G) {
   return agx::cdiv(N, rpc);
 }
 
-int colstats_run(hipStream_t st, const float *x, int ldx, int N, int G, float *mean, float *std, double *ws,
+template <typename T>
+int colstats_run(hipStream_t st, const T *x, int ldx, int N, int G, T *mean, T *std, double *ws,
                  int chunks) {
   const int gx = agx::cdiv(G, 64);
   const int rpc = agx::cdiv(N, chunks);
   chunks = agx::cdiv(N, rpc);
-  hipLaunchKernelGGL(colstats_partial_kernel, dim3(gx, chunks), dim3(256), 0, st, x, ldx, N, G, rpc, ws);
+  hipLaunchKernelGGL(colstats_partial_kernel<T>, dim3(gx, chunks), dim3(256), 0, st, x, ldx, N, G, rpc, ws);
   AGX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colstats_finish_kernel, dim3(agx::cdiv(G, 256)), dim3(256), 0, st, ws, chunks, x, N, G,
+  hipLaunchKernelGGL(colstats_finish_kernel<T>, dim3(agx::cdiv(G, 256)), dim3(256), 0, st, ws, chunks, x, N, G,
                      mean, std);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
@@ -355,7 +361,7 @@ extern "C" int agx_standardize(void *stream, const float *x, int32_t ldx, int32_
   hipStream_t st = agx::as_stream(stream);
   for (int r0 = 0; r0 < N; r0 += 65535) {  // gridDim.y limit
     const int rows = std::min(65535, N - r0);
-    hipLaunchKernelGGL(standardize_kernel, dim3(std::min(agx::cdiv(G, 256), 32), rows), dim3(256),
+    hipLaunchKernelGGL(standardize_kernel<float>, dim3(std::min(agx::cdiv(G, 256), 32), rows), dim3(256),
                        0, st, x + (size_t)r0 * ldx, ldx, G, mean, std, out + (size_t)r0 * ldo, ldo);
     AGX_LAUNCH_CHECK();
   }
@@ -403,7 +409,7 @@ extern "C" int agx_pearson_sums(void *stream, const float *a, const float *b, in
   int blocks = (int)std::min<int64_t>(agx::cdiv64(n, 256 * 8), 2048);
   if (blocks < 1) blocks = 1;
   hipStream_t st = agx::as_stream(stream);
-  hipLaunchKernelGGL(pearson_sums_kernel, dim3(blocks), dim3(256), 0, st, a, b, (long long)n, one_minus, ws);
+  hipLaunchKernelGGL(pearson_sums_kernel<float>, dim3(blocks), dim3(256), 0, st, a, b, (long long)n, one_minus, ws);
   AGX_LAUNCH_CHECK();
   return sums_finish(st, ws, blocks, 5, sums);
 }
@@ -413,7 +419,7 @@ extern "C" int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const 
   AGX_CHECK_ARG(C1 && C2 && sums && ws && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums: bad argument");
   hipStream_t st = agx::as_stream(stream);
   const int blocks = std::min(G, 2048);
-  hipLaunchKernelGGL(gamma_sums_kernel, dim3(blocks), dim3(256), 0, st, C1, ld1, C2, ld2, G, ws);
+  hipLaunchKernelGGL(gamma_sums_kernel<float>, dim3(blocks), dim3(256), 0, st, C1, ld1, C2, ld2, G, ws);
   AGX_LAUNCH_CHECK();
   return sums_finish(st, ws, blocks, 6, sums);
 }
@@ -430,6 +436,130 @@ extern "C" int agx_gamma_sums_tiles(void *stream, const float *C1, int32_t ld1, 
   const int blocks = (int)std::min<int64_t>(tile_end - tile_begin, 2048);
   hipLaunchKernelGGL(gamma_sums_tiles_kernel, dim3(blocks), dim3(256), 0, st, C1, ld1, C2, ld2, G,
                      (long long)tile_begin, (long long)tile_end, agx::cdiv(G, 128), ws);
+  AGX_LAUNCH_CHECK();
+  return sums_finish(st, ws, blocks, 6, sums);
+}
+
+
+// ---------------------------------------------------------------------------
+// float64 inputs: the reference computes in the input's dtype (utils.py:816-824: np.mean / np.std / np.dot of
+// float64 arrays, the E. coli notebook path), so float64 matrices take a float64 path end to end: the same
+// two-stage statistics, and X^T Y / N on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  One wave computes a
+// 32 x 32 block of C (2 x 2 MFMA tiles) over all N samples, fragments straight from global memory: at the
+// shapes float64 callers have (N <= 1000, G <= 4297: 25 GFLOP) the kernel is L2-bound at a few milliseconds.
+// ---------------------------------------------------------------------------
+namespace {
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// C[G1, G2] = alpha * X^T Y;  X [N, G1] ldx, Y [N, G2] ldy (row = sample)
+__global__ void __launch_bounds__(256) xty_f64_kernel(const double *__restrict__ X, int ldx,
+                                                      const double *__restrict__ Y, int ldy, int N, int G1,
+                                                      int G2, double alpha, double *__restrict__ C, int ldc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_n = (G2 + 31) / 32;
+  const long long t = (long long)blockIdx.x * 4 + wave;
+  const int i0 = (int)(t / tiles_n) * 32, j0 = (int)(t % tiles_n) * 32;
+  if (i0 >= G1) return;
+  const int c16 = lane & 15, k4 = lane >> 4;     // operand element: column c16 of the 16-wide tile, sample k4 of the 4
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  int ci[2], cj[2];
+  bool vi[2], vj[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    ci[a] = i0 + 16 * a + c16; vi[a] = ci[a] < G1; ci[a] = min(ci[a], G1 - 1);
+    cj[a] = j0 + 16 * a + c16; vj[a] = cj[a] < G2; cj[a] = min(cj[a], G2 - 1);
+  }
+  for (int n0 = 0; n0 < N; n0 += 4) {
+    const int n = n0 + k4;
+    const bool vn = n < N;
+    const size_t r = (size_t)min(n, N - 1);
+    double xa[2], yb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const double xv = X[r * ldx + ci[a]], yv = Y[r * ldy + cj[a]];
+      xa[a] = (vn && vi[a]) ? xv : 0.0;
+      yb[a] = (vn && vj[a]) ? yv : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a], yb[b], acc[a][b], 0, 0, 0);
+  }
+  // C/D map of the fp64 16x16 tile: column = lane & 15, register e holds row 4*e + (lane >> 4)
+  // (unlike the fp32 tiles, whose registers hold four CONSECUTIVE rows)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = j0 + 16 * b + c16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = i0 + 16 * a + 4 * e + k4;
+        if (row < G1 && col < G2) C[(size_t)row * ldc + col] = acc[a][b][e] * alpha;
+      }
+    }
+}
+}  // namespace
+
+extern "C" int agx_colstats_f64(void *stream, const double *x, int32_t ldx, int32_t N, int32_t G, double *mean,
+                                double *std, double *ws, int64_t ws_doubles) {
+  AGX_CHECK_ARG(x && mean && std && ws, "agx_colstats_f64: null argument");
+  AGX_CHECK_ARG(N > 0 && G > 0 && ldx >= G, "agx_colstats_f64: bad shape N=%d G=%d ldx=%d", N, G, ldx);
+  const int chunks = colstats_chunks(N, G);
+  if (ws_doubles < (int64_t)2 * G * chunks) {
+    agx::set_error("agx_colstats_f64: workspace of %lld doubles < agx_colstats_ws_doubles(%d, %d)", (long long)ws_doubles, N, G);
+    return AGX_E_WORKSPACE;
+  }
+  return colstats_run<double>(agx::as_stream(stream), x, ldx, N, G, mean, std, ws, chunks);
+}
+
+extern "C" int agx_standardize_f64(void *stream, const double *x, int32_t ldx, int32_t N, int32_t G,
+                                   const double *mean, const double *std, double *out, int32_t ldo) {
+  AGX_CHECK_ARG(x && mean && std && out, "agx_standardize_f64: null argument");
+  AGX_CHECK_ARG(N >= 0 && G > 0 && ldx >= G && ldo >= G, "agx_standardize_f64: bad shape");
+  hipStream_t st = agx::as_stream(stream);
+  for (int r0 = 0; r0 < N; r0 += 65535) {
+    const int rows = std::min(65535, N - r0);
+    hipLaunchKernelGGL(standardize_kernel<double>, dim3(std::min(agx::cdiv(G, 256), 32), rows), dim3(256), 0, st,
+                       x + (size_t)r0 * ldx, ldx, G, mean, std, out + (size_t)r0 * ldo, ldo);
+    AGX_LAUNCH_CHECK();
+  }
+  return AGX_OK;
+}
+
+extern "C" int agx_corr_xty_f64(void *stream, const double *xs, int32_t ldx, const double *ys, int32_t ldy, int32_t N,
+                                int32_t G1, int32_t G2, double alpha, double *C, int32_t ldc) {
+  AGX_CHECK_ARG(xs && ys && C && N > 0 && G1 > 0 && G2 > 0 && ldx >= G1 && ldy >= G2 && ldc >= G2,
+                "agx_corr_xty_f64: bad argument");
+  const long long tiles = (long long)agx::cdiv(G1, 32) * agx::cdiv(G2, 32);
+  hipLaunchKernelGGL(xty_f64_kernel, dim3((unsigned)agx::cdiv64(tiles, 4)), dim3(256), 0, agx::as_stream(stream), xs, ldx,
+                     ys, ldy, N, G1, G2, alpha, C, ldc);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_pearson_sums_f64(void *stream, const double *a, const double *b, int64_t n, int32_t one_minus,
+                                    double *sums, double *ws) {
+  AGX_CHECK_ARG(a && b && sums && ws && n >= 0, "agx_pearson_sums_f64: bad argument");
+  if (n == 0) return AGX_OK;
+  int blocks = (int)std::min<int64_t>(agx::cdiv64(n, 256 * 8), 2048);
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = agx::as_stream(stream);
+  hipLaunchKernelGGL(pearson_sums_kernel<double>, dim3(blocks), dim3(256), 0, st, a, b, (long long)n, one_minus, ws);
+  AGX_LAUNCH_CHECK();
+  return sums_finish(st, ws, blocks, 5, sums);
+}
+
+extern "C" int agx_gamma_sums_f64(void *stream, const double *C1, int32_t ld1, const double *C2, int32_t ld2, int32_t G,
+                                  double *sums, double *ws) {
+  AGX_CHECK_ARG(C1 && C2 && sums && ws && G > 0 && ld1 >= G && ld2 >= G, "agx_gamma_sums_f64: bad argument");
+  hipStream_t st = agx::as_stream(stream);
+  const int blocks = std::min(G, 2048);
+  hipLaunchKernelGGL(gamma_sums_kernel<double>, dim3(blocks), dim3(256), 0, st, C1, ld1, C2, ld2, G, ws);
   AGX_LAUNCH_CHECK();
   return sums_finish(st, ws, blocks, 6, sums);
 }

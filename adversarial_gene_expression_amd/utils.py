@@ -5,9 +5,10 @@ Same names, argument meaning and error behaviour as the reference
 kernels of libagx.so on an MI355X.  NumPy in -> NumPy out, like the reference.
 Device tensors (torch, cuda) in -> ``DeviceArray`` out (no host round trip).
 
-Precision note: the kernels compute in fp32 (exact-fp32 MFMA).  float64 inputs
-(the reference then computes in float64) are accepted, computed in fp32 and
-returned as float64, i.e. they agree with the reference to fp32 accuracy only.
+Precision: like NumPy, the arithmetic follows the input dtype.  float32 inputs take
+the fp32 path (exact-fp32 MFMA, the throughput path); float64 inputs (the reference's
+E. coli notebooks pass float64) take a float64 path end to end (fp64 matrix cores,
+``agx_*_f64``), so they agree with the reference to float64 rounding.
 """
 import numpy as np
 import torch
@@ -29,9 +30,83 @@ def _out(t, like_dev, dtype):
 
 def _in_dtype(*arrs):
     for a in arrs:
-        if isinstance(a, np.ndarray) and a.dtype == np.float64:
+        if isinstance(a, DeviceArray):
+            a = a.tensor
+        if (isinstance(a, np.ndarray) and a.dtype == np.float64) or (isinstance(a, torch.Tensor) and a.dtype == torch.float64):
             return np.float64
     return np.float32
+
+
+# ---------------------------------------------------------------------------
+# float64 building blocks (reference dtype semantics: float64 in -> float64 arithmetic)
+# ---------------------------------------------------------------------------
+
+def _mat64(a):
+    t = _dev.to_dev(a, torch.float64)
+    if t.dim() != 2:
+        raise ValueError('expected a 2-D matrix, got shape %s' % (tuple(t.shape),))
+    return t
+
+
+def _colstats_dev64(xd):
+    lib = _lib.load()
+    n, g = xd.shape
+    mean, std = _dev.empty(g, dtype=torch.float64), _dev.empty(g, dtype=torch.float64)
+    nws = int(lib.agx_colstats_ws_doubles(n, g))
+    ws = _dev.empty(nws, dtype=torch.float64)
+    _lib.check(lib.agx_colstats_f64(_dev.stream(), ptr(xd), xd.stride(0), n, g, ptr(mean), ptr(std), ptr(ws), nws),
+               'agx_colstats_f64')
+    return mean, std
+
+
+def _standardize_dev64(xd, mean, std):
+    lib = _lib.load()
+    n, g = xd.shape
+    out = _dev.empty((n, g), dtype=torch.float64)
+    _lib.check(lib.agx_standardize_f64(_dev.stream(), ptr(xd), xd.stride(0), n, g, ptr(mean), ptr(std), ptr(out), g),
+               'agx_standardize_f64')
+    return out
+
+
+def _corr_dev64(x, y=None):
+    """Pearson matrix of float64 columns (x with itself when y is None): device tensor [G1, G2] float64."""
+    lib = _lib.load()
+    xd = _mat64(x)
+    xs = _standardize_dev64(xd, *_colstats_dev64(xd))
+    if y is None:
+        ys = xs
+    else:
+        yd = _mat64(y)
+        ys = _standardize_dev64(yd, *_colstats_dev64(yd))
+    n, g1, g2 = xs.shape[0], xs.shape[1], ys.shape[1]
+    c = _dev.empty((g1, g2), dtype=torch.float64)
+    _lib.check(lib.agx_corr_xty_f64(_dev.stream(), ptr(xs), g1, ptr(ys), g2, n, g1, g2, 1.0 / n, ptr(c), g2),
+               'agx_corr_xty_f64')
+    return c
+
+
+def _r_from_sums64(s, n):
+    with np.errstate(all='ignore'):
+        ma, mb = s[0] / n, s[1] / n
+        va, vb = s[2] / n - ma * ma, s[3] / n - mb * mb
+        cov = s[4] / n - ma * mb
+        return np.float64(cov / (np.sqrt(max(va, 0.0)) * np.sqrt(max(vb, 0.0))))
+
+
+def _gamma_coef64(x, y):
+    """gamma_coef for float64 inputs (every rank computes the whole matrices: float64 callers are small)."""
+    lib = _lib.load()
+    cx, cy = _corr_dev64(x), _corr_dev64(y)
+    g = cx.shape[0]
+    sums = _dev.zeros(8, dtype=torch.float64)
+    _lib.check(lib.agx_gamma_sums_f64(_dev.stream(), ptr(cx), g, ptr(cy), g, g, ptr(sums), ptr(_sums_ws())),
+               'agx_gamma_sums_f64')
+    s = sums.cpu().numpy()
+    if s[5] == 0:
+        return _r_from_sums64(s, g * (g - 1) // 2)
+    lx, ly = _triu_pack_dev(cx, g, g), _triu_pack_dev(cy, g, g)
+    assert lx.shape[0] == ly.shape[0]
+    return np.float64(_pearson_1d_dev(lx, ly, one_minus=True))
 
 
 # ---------------------------------------------------------------------------
@@ -102,6 +177,10 @@ def _pearson_1d_dev(a, b, one_minus=False):
     lib = _lib.load()
     n = a.numel()
     sums = _dev.zeros(8, dtype=torch.float64)
+    if a.dtype == torch.float64:
+        _lib.check(lib.agx_pearson_sums_f64(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums), ptr(_sums_ws())),
+                   'agx_pearson_sums_f64')
+        return _r_from_sums64(sums.cpu().numpy(), n)
     _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums), ptr(_sums_ws())),
                'agx_pearson_sums')
     return _r_from_sums(sums.cpu().numpy(), n)
@@ -138,9 +217,16 @@ def _triu_pack_dev(c, ldc, g):
 
 def standardize(x, mean=None, std=None):
     """Shape x: (nb_samples, nb_vars).  Reference ``utils.py:260-268``."""
-    lib = _lib.load()
     dev_in = _is_dev(x)
     dt = _in_dtype(x)
+    if dt == np.float64:
+        xd = _mat64(x)
+        g = xd.shape[1]
+        if mean is None or std is None:
+            m_, s_ = _colstats_dev64(xd)
+        mean_d = m_ if mean is None else _dev.to_dev(np.broadcast_to(np.asarray(mean, np.float64), (g,)), torch.float64)
+        std_d = s_ if std is None else _dev.to_dev(np.broadcast_to(np.asarray(std, np.float64), (g,)), torch.float64)
+        return _out(_standardize_dev64(xd, mean_d, std_d), dev_in, dt)
     xd, ld = _dev.padded_matrix(x)
     n, g = xd.shape[0], (x.shape[1])
     if mean is None or std is None:
@@ -166,8 +252,10 @@ def pearson_correlation(x, y):
     dev_in = _is_dev(x)
     dt = _in_dtype(x, y)
     if len(x.shape) == 1:
-        r = _pearson_1d_dev(_dev.to_dev(x).reshape(-1), _dev.to_dev(y).reshape(-1))
-        return r if dt == np.float32 else np.float64(r)
+        td = torch.float64 if dt == np.float64 else torch.float32
+        return _pearson_1d_dev(_dev.to_dev(x, td).reshape(-1), _dev.to_dev(y, td).reshape(-1))
+    if dt == np.float64:
+        return _out(_corr_dev64(x, None if x is y else y), dev_in, dt)
     if x is y:
         c, ldc, g = _corr_self_dev(x)
         return _out(c[:, :g], dev_in, dt)
@@ -191,6 +279,9 @@ def upper_diag_list(m_):
 
 def correlations_list(x, y, corr_fn=pearson_correlation):
     """Reference ``utils.py:852-860``."""
+    if corr_fn is pearson_correlation and x is y and _in_dtype(x) == np.float64:
+        c = _corr_dev64(x)
+        return _out(_triu_pack_dev(c, c.shape[1], c.shape[0]), _is_dev(x), np.float64)
     if corr_fn is pearson_correlation and x is y:
         dev_in = _is_dev(x)
         c, ldc, g = _corr_self_dev(x)
@@ -225,6 +316,8 @@ def gamma_coef(x, y):
     if x.shape[1] != y.shape[1]:
         # lists of different length: reference fails at utils.py:821
         raise AssertionError
+    if dt == np.float64:
+        return _gamma_coef64(x, y)
     tb, te, world = _rank_tile_range(x.shape[1])
     sums = _dev.zeros(8, dtype=torch.float64)
     if world > 1:
@@ -267,6 +360,9 @@ class GammaScorer:
     def __init__(self, x_test):
         self.dtype = _in_dtype(x_test)
         self.g = x_test.shape[1]
+        if self.dtype == np.float64:      # float64 test set: float64 arithmetic, matrix of the fixed side cached
+            self.world, self._x, self.cx = 1, None, _corr_dev64(x_test)
+            return
         self.tb, self.te, self.world = _rank_tile_range(self.g)
         self._x = x_test if self.world > 1 else None     # NaN fallback of the sharded path needs the input again
         rng = (self.tb, self.te) if self.world > 1 else None
@@ -279,6 +375,16 @@ class GammaScorer:
             raise AssertionError
         sums = _dev.zeros(8, dtype=torch.float64)
         g = self.g
+        if self.dtype == np.float64:
+            cy = _corr_dev64(_dev.to_dev(x_gen, torch.float64))
+            _lib.check(lib.agx_gamma_sums_f64(_dev.stream(), ptr(self.cx), g, ptr(cy), g, g, ptr(sums), ptr(_sums_ws())),
+                       'agx_gamma_sums_f64')
+            s = sums.cpu().numpy()
+            if s[5] == 0:
+                return _r_from_sums64(s, g * (g - 1) // 2)
+            lx, ly = _triu_pack_dev(self.cx, g, g), _triu_pack_dev(cy, g, g)
+            assert lx.shape[0] == ly.shape[0]
+            return np.float64(_pearson_1d_dev(lx, ly, one_minus=True))
         if self.world > 1:
             cy, ldy, _ = _corr_self_dev(x_gen, (self.tb, self.te))
             _lib.check(lib.agx_gamma_sums_tiles(_dev.stream(), ptr(self.cx), self.ldx, ptr(cy), ldy, g, self.tb, self.te,

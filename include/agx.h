@@ -322,6 +322,22 @@ int agx_gamma_sums(void *stream, const float *C1, int32_t ld1, const float *C2, 
 int agx_gamma_sums_tiles(void *stream, const float *C1, int32_t ld1, const float *C2, int32_t ld2,
                          int32_t G, int64_t tile_begin, int64_t tile_end, double *sums, double *ws);
 
+/* float64 inputs: the reference computes in the dtype it is given (utils.py:816-824 on float64 arrays, the
+ * E. coli notebook path), so float64 matrices take a float64 path end to end - same two-stage statistics,
+ * X^T Y / N on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), fp64 sums for gamma.  Sized for the shapes
+ * float64 callers have (N <= ~1000 samples, G <= ~4300 genes); the fp32 path above is the throughput path. */
+int agx_colstats_f64(void *stream, const double *x, int32_t ldx, int32_t N, int32_t G, double *mean,
+                     double *std, double *ws, int64_t ws_doubles);
+int agx_standardize_f64(void *stream, const double *x, int32_t ldx, int32_t N, int32_t G,
+                        const double *mean, const double *std, double *out, int32_t ldo);
+/* C[G1, G2] = alpha * xs^T ys  (utils.py:824; pass the same pointer twice for the self-correlation) */
+int agx_corr_xty_f64(void *stream, const double *xs, int32_t ldx, const double *ys, int32_t ldy, int32_t N,
+                     int32_t G1, int32_t G2, double alpha, double *C, int32_t ldc);
+int agx_pearson_sums_f64(void *stream, const double *a, const double *b, int64_t n, int32_t one_minus,
+                         double *sums, double *ws);
+int agx_gamma_sums_f64(void *stream, const double *C1, int32_t ld1, const double *C2, int32_t ld2, int32_t G,
+                       double *sums, double *ws);
+
 /* ---- whole train step: tf_utils.py:186-258 ------------------------------ */
 typedef struct agx_mlp_desc {
   int32_t n_layers;                 /* Dense layers incl. the output layer      */

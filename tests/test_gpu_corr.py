@@ -1,7 +1,8 @@
 """Correlation / gamma path on the GPU against the reference's golden vectors and the NumPy oracle.
 
-Tolerances (fp32): Pearson matrix |err| <= 3e-6 for N <= 300 (fp32 fma chain over N products of
-O(1) terms, then /N), gamma <= 2e-5."""
+Tolerances: float32 inputs - Pearson matrix |err| <= 3e-6 for N <= 300 (fp32 fma chain over N products of
+O(1) terms, then /N), gamma <= 2e-5; float64 inputs (the reference then computes in float64, and so does
+the agx_*_f64 path) - 1e-12 on the matrix, 1e-10 on gamma."""
 import glob
 import os
 
@@ -21,8 +22,9 @@ def test_against_reference_goldens(gpu, name):
     from adversarial_gene_expression_amd import utils as U
     g = golden(name)
     x, y, y2 = g['x'], g['y'], g['y2']
-    # float64 inputs are computed in fp32 on the MFMA path (documented in utils.py): fp32 tolerance
-    tol = 3e-6
+    f64 = x.dtype == np.float64
+    tol = 1e-12 if f64 else 3e-6
+    gtol = 1e-10 if f64 else 2e-5
     pxx = U.pearson_correlation(x, x)
     assert pxx.dtype == x.dtype and pxx.shape == g['pearson_xx'].shape
     np.testing.assert_allclose(pxx, g['pearson_xx'], rtol=0, atol=tol, equal_nan=True)
@@ -31,18 +33,22 @@ def test_against_reference_goldens(gpu, name):
     cl = U.correlations_list(x, x)
     assert cl.shape == g['corr_list_xx'].shape
     np.testing.assert_allclose(cl, g['corr_list_xx'], rtol=0, atol=tol)
-    np.testing.assert_allclose(U.standardize(x), g['standardize_x'], rtol=2e-5, atol=2e-6, equal_nan=True)
+    np.testing.assert_allclose(U.standardize(x), g['standardize_x'], rtol=1e-12 if f64 else 2e-5,
+                               atol=1e-12 if f64 else 2e-6, equal_nan=True)
     np.testing.assert_allclose(U.standardize(x, mean=np.mean(y, axis=0), std=np.std(y, axis=0)),
-                               g['standardize_x_with_y_stats'], rtol=1e-6, atol=1e-6)
+                               g['standardize_x_with_y_stats'], rtol=1e-12 if f64 else 1e-6, atol=1e-12 if f64 else 1e-6)
     tr, te = U.split_train_test(x)
     np.testing.assert_array_equal(tr, g['split_train'])
     np.testing.assert_array_equal(te, g['split_test'])
-    np.testing.assert_allclose(U.pearson_correlation(g['a1d'], g['b1d']), g['pearson_1d'], atol=2e-6)
-    np.testing.assert_allclose(U.gamma_coef(x, x), g['gamma_x_x'], atol=2e-5)
+    r1 = U.pearson_correlation(g['a1d'], g['b1d'])
+    assert r1.dtype == g['pearson_1d'].dtype
+    np.testing.assert_allclose(r1, g['pearson_1d'], atol=1e-12 if g['a1d'].dtype == np.float64 else 2e-6)
+    np.testing.assert_allclose(U.gamma_coef(x, x), g['gamma_x_x'], atol=gtol)
     if 'gamma_x_y2' in g.files:
         got = U.gamma_coef(x, y2)
         assert got.dtype == g['gamma_x_y2'].dtype
-        np.testing.assert_allclose(got, g['gamma_x_y2'], atol=2e-5)
+        np.testing.assert_allclose(got, g['gamma_x_y2'], atol=gtol)
+        assert abs(float(U.GammaScorer(x)(y2)) - float(g['gamma_x_y2'])) <= gtol
 
 
 def test_upper_diag_list_drops_genuine_nans(gpu):
@@ -67,6 +73,27 @@ def test_against_oracle_ecoli_shapes(gpu, N, G):
     np.testing.assert_array_equal(U.upper_diag_list(CO.pearson_correlation(x, x)),
                                   CO.upper_diag_list(CO.pearson_correlation(x, x)))
     np.testing.assert_allclose(U.gamma_coef(x, y), CO.gamma_coef_f64(x, y), atol=2e-5)
+
+
+@pytest.mark.parametrize('N,G', [(227, 1076), (680, 4297)])
+def test_float64_inputs_take_the_float64_path(gpu, N, G):
+    """The E. coli notebooks pass float64 matrices; the reference then computes in float64 (utils.py:816-824).
+    Raw (un-centred) log-expression-like values, bipartite and self correlation, gamma."""
+    from adversarial_gene_expression_amd import utils as U
+    rs = np.random.RandomState(N)
+    x = lowrank(rs, N, G, k=16).astype(np.float64) * 0.7 + 6.0
+    y = lowrank(rs, N // 2 + 3, G, k=16).astype(np.float64) * 0.7 + 6.0
+    got = U.pearson_correlation(x, x)
+    assert got.dtype == np.float64
+    np.testing.assert_allclose(got, CO.pearson_correlation(x, x), rtol=0, atol=1e-12)
+    z = x[:, :300] + 0.1 * rs.randn(N, 300)
+    np.testing.assert_allclose(U.pearson_correlation(x, z), CO.pearson_correlation(x, z), rtol=0, atol=1e-12)
+    want = CO.gamma_coef(x, y)
+    got = U.gamma_coef(x, y)
+    assert got.dtype == np.float64 and abs(float(got) - float(want)) < 1e-10
+    cl = U.correlations_list(x, x)
+    np.testing.assert_allclose(cl, CO.correlations_list(x, x), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(U.standardize(x), CO.standardize(x), rtol=1e-12, atol=1e-12)
 
 
 def test_unshifted_data_is_centred_before_the_product(gpu):
