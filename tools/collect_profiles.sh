@@ -12,7 +12,7 @@ timeout -k 10 600 python3 bench.py > $O/${tag}_bench.json.log 2> $O/${tag}_bench
 for b in 32 512; do
   d=$O/prof_${tag}_$b
   rm -rf $d
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python3 bench.py --no-cpu-baseline --no-secondary --corr-n 0 --steps 40 --warmup 5 --batch $b > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python3 bench.py --no-cpu-baseline --no-secondary --no-extra --corr-n 0 --steps 40 --warmup 5 --batch $b > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   python3 tools/trace_timeline.py $(find $d -name '*kernel_trace.csv' | head -1) > $O/${tag}_timeline_b$b.txt
   cp $(find $d -name '*kernel_stats.csv' | head -1) $O/${tag}_b${b}_kernel_stats.csv
   rm -rf $d $d.log
@@ -22,7 +22,7 @@ for b in 32 512; do
   for c in FETCH_SIZE WRITE_SIZE; do
     d=$O/pmc_${tag}_${c}_$b
     rm -rf $d
-    timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $d -o p -- python3 bench.py --no-secondary --no-cpu-baseline --steps 2 --warmup 1 --batch $b --corr-n 0 > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+    timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $d -o p -- python3 bench.py --no-secondary --no-extra --no-cpu-baseline --steps 2 --warmup 1 --batch $b --corr-n 0 > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
     cp $(find $d -name '*counter_collection.csv' | head -1) $O/${tag}_pmc_${c}_b$b.csv
     rm -rf $d $d.log
   done
