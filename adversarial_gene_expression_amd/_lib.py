@@ -237,6 +237,11 @@ def load():
         raise AgxError('libagx.so not found at %s - build it with `python -c "import __graft_entry__ as g; '
                        'g.build()"` or `make -C adversarial_gene_expression_amd/csrc`; there is no CPU '
                        'fallback' % LIB_PATH)
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so).  Loading libagx.so FIRST would pull in the
+    # system one (/opt/rocm) beside it, and whichever of the two runtimes opens the device second then reports
+    # "no ROCm-capable device" (measured on the MI355X box).  With torch imported first libagx binds to the
+    # runtime already in the process: one runtime, shared streams and allocations.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
