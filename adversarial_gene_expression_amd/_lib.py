@@ -153,6 +153,7 @@ SIGNATURES = {
     'agx_prof_empty_bracket_us': (C.c_int, [_vp, _i32, C.POINTER(C.c_double)]),
     'agx_prof_enabled': (C.c_int, []),
     'agx_prof_clock': (C.c_int, [_vp, _i32, _i32, _vp]),
+    'agx_prof_occupancy': (C.c_int, [_i32, C.POINTER(_i32), C.POINTER(_i32)]),
     'agx_sizeof': (_i64, [_i32]),
     'agx_gemm_f32': (C.c_int, [_vp, C.POINTER(GemmDesc)]),
     'agx_gemm_ws_floats': (_i64, [_i32, _i32, _i32]),

@@ -19,6 +19,7 @@
 #include "agx_common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -205,19 +206,28 @@ __device__ __forceinline__ float epilogue_store(const KParams &p, int row, int c
 // Same epilogue for NV values of ONE column: all side loads (bias, addrow, mask, old C) are issued
 // up front with clamped (always valid) indices, so they overlap instead of one round trip each.
 // Returns the stored values in v (0 for elements outside the matrix).
+// pre: the column's {bias, col_scale, col_shift} already in registers (a caller that stores several sub-tiles
+// must request them BEFORE its first store: vmcnt retires in issue order, so a load issued behind the stores of
+// the previous sub-tile waits for their write acknowledgements - measured 25 us of epilogue per 128x128 tile).
 template <int NV, bool OPT = false>
 __device__ __forceinline__ void epilogue_column(const KParams &p, const int (&rows)[NV], int col,
-                                                float (&v)[NV]) {
+                                                float (&v)[NV], const float *pre = nullptr) {
   const int cc = min(col, p.N - 1);
   const bool colok = col < p.N;
   float bias = 0.f, csc = 1.f, csh = 0.f, add[NV], mk[NV], old[NV], rs[NV];
   int cr[NV];
 #pragma unroll
   for (int e = 0; e < NV; ++e) cr[e] = min(rows[e], p.M - 1);
-  if (p.bias) bias = p.bias[cc];
-  if (p.col_scale) {
-    csc = p.col_scale[cc];
-    csh = p.col_shift[cc];
+  if (pre) {
+    bias = pre[0];
+    csc = pre[1];
+    csh = pre[2];
+  } else {
+    if (p.bias) bias = p.bias[cc];
+    if (p.col_scale) {
+      csc = p.col_scale[cc];
+      csh = p.col_shift[cc];
+    }
   }
   if (p.rowscale) {
 #pragma unroll
@@ -451,11 +461,40 @@ struct Tile {
 
 using agx::tri_decode;
 
+#ifdef AGX_STAMPS
+// diagnostic build only (tools/stamps.py): per-workgroup phase stamps of gemm_kernel, 8 x int64 per workgroup
+// [start, first tile staged, main loop done, epilogue issued, stores drained, HW_ID, XCC_ID, tile]
+__device__ long long *g_stamps = nullptr;
+__device__ int g_stamp_m = -1, g_stamp_k = -1;   // only launches of this M / K are recorded (-1: any)
+#define AGX_STAMP_ON (g_stamps && threadIdx.x == 0 && (g_stamp_m < 0 || p.M == g_stamp_m) && (g_stamp_k < 0 || p.K == g_stamp_k))
+#define AGX_STAMP(i) \
+  if (AGX_STAMP_ON) stamp_v[i] = (long long)__builtin_amdgcn_s_memrealtime()
+#else
+#define AGX_STAMP(i)
+#endif
+
+#ifndef AGX_WPE_SMALL
+#define AGX_WPE_SMALL 1
+#endif
+#ifndef AGX_WPE_W8
+#define AGX_WPE_W8 1
+#endif
+#ifndef AGX_OPTI_WPE
+#define AGX_OPTI_WPE 1
+#endif
+// resident waves per SIMD the register allocator must leave room for (512 registers per SIMD lane, VGPR+AGPR):
+// two 4-wave 128x128 workgroups per CU (<= 256 registers) - one multiplies while the other loads or stores
+constexpr int gemm_min_waves(int bm, int bn, int wm, int wn, bool opt, bool opti) {
+  return (opt && opti) ? AGX_OPTI_WPE
+                       : ((bm * bn <= 64 * 64 || bm * bn == 32 * 128) ? AGX_WPE_SMALL : (wm * wn == 8 ? AGX_WPE_W8 : 2));
+}
+
 // OPTI: the fused-optimizer epilogue and its prefetch take a clamp-free path on interior tiles (its own
 // instantiation: compiled into the K = 1536 launches the same source measured 1-2 % SLOWER per iteration)
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, int DBG = 0,
           bool OPT = false, bool OPTI = false>
-__global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
+__global__ void __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(gemm_min_waves(BM, BN, WM, WN, OPT, OPTI))))
+gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -464,6 +503,10 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   constexpr int STAGE = TileA::LDS_FLOATS + TileB::LDS_FLOATS;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef AGX_STAMPS
+  long long stamp_v[5] = {0, 0, 0, 0, 0};
+#endif
+  AGX_STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -491,7 +534,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
     tri_decode(p.tile_begin + agx::xcd_logical_id(blockIdx.x, gridDim.x), p.tiles_1d, tm, tn);
     z = 0;
   } else {
-    // logical order: split-K slice major, then tile row, then tile column
+    // logical order: split-K slice major, then the tiles row-major (a column-major walk where its per-XCD range
+    // touches fewer operand bytes measured no different: 64.5 against 65.3 us on the 512-row input gradient)
     const int lid = agx::xcd_logical_id(blockIdx.x + gx * blockIdx.y, gx * gridDim.y);
     const int tiles_n = (p.N + BN - 1) / BN;
     const int t = lid % gx;
@@ -520,6 +564,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   // of this one-round grid over time, only added the delay: +4 us per launch per step of delay)
   float pw[OPT_PRE ? 16 : 1], ps[OPT_PRE ? 16 : 1];
   const bool opt_interior = OPT_PRE && OPTI && m0 + BM <= min(p.M, p.opt_rows) && n0 + BN <= p.N;
+  auto opt_prefetch = [&]() {
   if (opt_interior) {
     // interior tile: one 64-bit base, 32-bit row offsets, no clamps
     const size_t base = (size_t)(m0 + wm * 32 + 4 * lh) * p.ldc + (n0 + wn * 32 + l31);
@@ -541,15 +586,31 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
       ps[r] = p.opt_s1[off];
     }
   }
+  };
+  // (requesting the first two K-tiles BEFORE these operands - vmcnt retires in issue order - measured slower:
+  // 0.532 against 0.522 ms per 32-row iteration; so did moving them as dwordx4 through an LDS transposition)
+  opt_prefetch();
 
   float4 ra[TileA::PT], rb[TileB::PT];
+  int offa[TileA::PT], offb[TileB::PT];
+  const bool fast_tile = VEC && DBG == 0 && m0 + BM <= p.M && n0 + BN <= p.N;
+  const int nfull = (kend - kbeg) / BK;
   if (nt > 0) {
     TileA::load(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
     TileB::load(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
     TileA::store(smem, tid, ra, m0, p.M, kbeg, kend);
     TileB::store(smem + TileA::LDS_FLOATS, tid, rb, n0, p.N, kbeg, kend);
   }
+  if (fast_tile) {
+    TileA::lane_offsets(p.lda, tid, offa);
+    TileB::lane_offsets(p.ldb, tid, offb);
+    if (nfull > 1) {
+      TileA::load_fast(TileA::ubase(p.A, p.lda, m0, kbeg + BK), offa, ra);
+      TileB::load_fast(TileB::ubase(p.B, p.ldb, n0, kbeg + BK), offb, rb);
+    }
+  }
   __syncthreads();
+  AGX_STAMP(1);
 
   // MFMAs of one staged K-tile: per 8-k group one ds_read_b128 per fragment, then 4 x TM x TN MFMAs.
   // The reads of group g+1 are issued before the MFMAs of group g (register double buffer).
@@ -591,22 +652,14 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
   auto nothing = [] {};
 
   int t = 0;
-  if (VEC && DBG == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
+  if (fast_tile) {
     // interior tile: K-tiles 1 .. nfull-1 are loaded without clamps and stored without masks
     // (the first K-tile through the same path: no gain at K = 96, 0.4 % slower at K = 1536)
-    const int nfull = (kend - kbeg) / BK;
-    int offa[TileA::PT], offb[TileB::PT];
-    TileA::lane_offsets(p.lda, tid, offa);
-    TileB::lane_offsets(p.ldb, tid, offb);
     // Staging pipeline: the registers always hold the tile AFTER the one being multiplied.  Inside
     // iteration t, right after the first MFMA group, tile t+1 goes from the registers into the other
     // LDS buffer (free since the barrier that ended iteration t-1) and the loads of tile t+2 are
     // issued into the same registers: every global load has a whole iteration to land, and the
     // store / load instructions issue between MFMA groups instead of in front of the barrier.
-    if (nfull > 1) {
-      TileA::load_fast(TileA::ubase(p.A, p.lda, m0, kbeg + BK), offa, ra);
-      TileB::load_fast(TileB::ubase(p.B, p.ldb, n0, kbeg + BK), offb, rb);
-    }
     for (; t + 1 < nfull; ++t) {
       const float *cA = smem + (t & 1) * STAGE;
       float *nA = smem + ((t + 1) & 1) * STAGE;
@@ -651,7 +704,60 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
     __syncthreads();
   }
 
+  AGX_STAMP(2);
   // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // per-column epilogue operands of ALL sub-tiles, requested before the first store (see epilogue_column)
+  float epre[TN][3];
+  bool stored = false;
+  if (!SYRK && !OPT) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cc = min(n0 + (wn * TN + j) * 32 + l31, p.N - 1);
+      epre[j][0] = p.bias ? p.bias[cc] : 0.f;
+      epre[j][1] = p.col_scale ? p.col_scale[cc] : 1.f;
+      epre[j][2] = p.col_scale ? p.col_shift[cc] : 0.f;
+    }
+    // Raw split-K slabs and plain Dense products (alpha, bias, activation): ONE straight-line block of stores
+    // over all sub-tiles.  Inside the general per-sub-tile code below hipcc ends every sub-tile with
+    // s_waitcnt vmcnt(0) (its optional side loads meet there), i.e. a full drain of the sub-tile's stores before
+    // the next one starts: four write round trips per wave of a 128x128 tile, 25 us of epilogue per tile measured.
+    const bool plain = !p.rowscale && !p.addrow && !p.mask && !p.accumulate && !p.rowsq && !p.col_scale;
+    if (p.to_ws || plain) {
+      stored = true;
+      float *dst = p.C;
+      int ldd = p.ldc;
+      if (p.to_ws) {
+        dst = p.ws + (p.ws_by_row ? (size_t)z * p.N : (size_t)z * p.M * p.N);
+        ldd = p.ws_by_row ? p.splitk * p.N : p.N;
+      }
+      const bool raw = p.to_ws != 0;
+      auto store_all = [&](auto interior) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+            const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+            float *__restrict__ cb = dst + (size_t)rbase * ldd + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = (r & 3) + 8 * (r >> 2);
+              float x = acc[i][j][r];
+              if (!raw) {
+                x *= p.alpha;
+                if (p.bias) x += epre[j][0];
+                if (p.act) x = x > 0.f ? x : x * p.slope;
+              }
+              if (decltype(interior)::value || (rbase + ro < p.M && col < p.N)) cb[ro * ldd] = x;
+            }
+          }
+        }
+      };
+      if (m0 + BM <= p.M && n0 + BN <= p.N) store_all(std::true_type{});
+      else store_all(std::false_type{});
+    }
+  }
+  if (!stored) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -689,7 +795,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
           rows[r] = rbase + (r & 3) + 8 * (r >> 2);
           v[r] = acc[i][j][r];
         }
-        if (p.to_ws) {
+        if (p.to_ws) {   // (OPT instantiations only: the others took the block above)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (rows[r] < p.M && col < p.N) p.ws[slab_off(p, z, rows[r]) + col] = v[r];
@@ -720,20 +826,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
           }
         } else if (OPT) {
           epilogue_column<16, true>(p, rows, col, v);
-        } else if (OPTI && m0 + BM <= p.M && n0 + BN <= p.N && !p.rowscale && !p.addrow && !p.mask &&
-                   !p.accumulate && !p.rowsq && !p.col_scale) {
-          // interior tile of a plain Dense product (alpha, bias, activation): one base pointer, no clamps
-          const float bias = p.bias ? p.bias[col] : 0.f;
-          float *__restrict__ cb = p.C + (size_t)rbase * p.ldc + col;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float x = v[r] * p.alpha;
-            if (p.bias) x += bias;
-            if (p.act) x = x > 0.f ? x : x * p.slope;
-            cb[((r & 3) + 8 * (r >> 2)) * p.ldc] = x;
-          }
         } else {
-          epilogue_column<16>(p, rows, col, v);
+          epilogue_column<16>(p, rows, col, v, epre[j]);
           if (p.rowsq) {  // deterministic per-slab partial of sum_col v^2 (only without split-K)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -746,6 +840,19 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_kernel(const KParams p) {
       }
     }
   }
+  }
+#ifdef AGX_STAMPS
+  AGX_STAMP(3);
+  __builtin_amdgcn_s_waitcnt(0);
+  AGX_STAMP(4);
+  if (AGX_STAMP_ON) {
+    long long *o = g_stamps + 8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+    for (int i = 0; i < 5; ++i) o[i] = stamp_v[i];
+    o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    o[7] = tm * 100000 + tn * 100 + z;
+  }
+#endif
 }
 
 // Split-K reduction + epilogue.  blockDim 256 = (256/PH lanes over 4-element chunks) x (PH split
@@ -1200,10 +1307,6 @@ int launch_layout(hipStream_t st, const KParams &p, int tiles, int ta, int tb, b
              : launch<BM, BN, WM, WN, true, false, false, false, BK>(st, p, tiles);
 }
 
-bool fast_epi() {
-  static const bool v = getenv("AGX_NO_FAST_EPI") == nullptr;
-  return v;
-}
 
 struct Plan {
   int cfg, bm, bn, tiles, splitk, kchunk;
@@ -1313,7 +1416,6 @@ int gemm_prepare_device() {
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true, true>()));
-  AGX_TRY((prepare_one<64, 64, 2, 2, false, false, true, false, 32, false, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true, true>()));
   return AGX_OK;
 }
@@ -1455,8 +1557,6 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
              : launch<64, 64, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
   else if (pl.cfg == 0)
     rc = launch_layout<128, 128, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
-  else if (pl.cfg == 1 && !g->ta && !g->tb && vec && g->K <= 512 && fast_epi())
-    rc = launch<64, 64, 2, 2, false, false, true, false, 32, false, true>(st, p, pl.tiles);
   else if (pl.cfg == 1)
     rc = launch_layout<64, 64, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 2)
@@ -1495,6 +1595,29 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   return AGX_OK;
 }
 
+// measurement only: resident workgroups per CU the runtime computes for the main tile configurations
+// which: 0 = 64x64 NT, 1 = 64x64 TN fused optimizer, 2 = 128x128 NN 8-wave, 3 = 128x128 SYRK, 4 = 64x64 NN
+extern "C" int agx_prof_occupancy(int32_t which, int32_t *blocks_per_cu, int32_t *lds_bytes) {
+  AGX_CHECK_ARG(blocks_per_cu && lds_bytes, "agx_prof_occupancy: null argument");
+  int nb = 0;
+  size_t lds = 0;
+  hipError_t e = hipErrorInvalidValue;
+  constexpr size_t l64 = 2 * (size_t)(64 * 32 + 64 * 32) * sizeof(float), l128 = 2 * (size_t)(128 * 32 + 128 * 32) * sizeof(float);
+  switch (which) {
+    case 0: lds = l64; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, false, true, true, false, 32, 0, false, false>, 256, lds); break;
+    case 1: lds = l64; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, true, false, true, false, 32, 0, true, false>, 256, lds); break;
+    case 2: lds = l128; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<128, 128, 2, 4, false, false, true, false, 32, 0, false, false>, 512, lds); break;
+    case 3: lds = l128; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<128, 128, 2, 2, true, false, true, true, 32, 0, false, false>, 256, lds); break;
+    case 4: lds = l64; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, false, false, true, false, 32, 0, false, false>, 256, lds); break;
+    case 5: lds = l128; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<128, 128, 2, 2, false, false, true, false, 32, 0, false, false>, 256, lds); break;
+    default: AGX_CHECK_ARG(false, "agx_prof_occupancy: which = %d", which);
+  }
+  AGX_HIP(e);
+  *blocks_per_cu = nb;
+  *lds_bytes = (int32_t)lds;
+  return AGX_OK;
+}
+
 extern "C" int64_t agx_corr_num_tiles(int32_t G) {
   const int64_t T = agx::cdiv(G, 128);
   return T * (T + 1) / 2;
@@ -1529,3 +1652,12 @@ extern "C" int agx_corr_xtx(void *stream, const float *xs, int32_t ldx, int32_t 
   return vec ? launch<128, 128, 2, 2, true, false, true, true>(st, p, tiles)
              : launch<128, 128, 2, 2, true, false, false, true>(st, p, tiles);
 }
+
+#ifdef AGX_STAMPS
+extern "C" int agx_dbg_stamps(long long *buf, int m, int k) {
+  AGX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)));
+  AGX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_m), &m, sizeof(m)));
+  AGX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_k), &k, sizeof(k)));
+  return AGX_OK;
+}
+#endif

@@ -75,6 +75,10 @@ int agx_prof_enabled(void);
 /* Clock probe: out_dev[0] = shader MHz seen by a kernel of `blocks` x 4 waves issuing `mfmas`
  * dependent 32x32x2 fp32 MFMAs each, out_dev[1] = cycles per MFMA (measurement only). */
 int agx_prof_clock(void *stream, int32_t blocks, int32_t mfmas, float *out_dev);
+/* Resident workgroups per CU the HIP runtime computes for a main tile configuration (0 = 64x64 NT, 1 = 64x64 TN with
+ * the fused optimizer, 2 = 128x128 NN 8-wave, 3 = 128x128 SYRK, 4 = 64x64 NN, 5 = 128x128 NN 4-wave) and its dynamic LDS
+ * bytes. */
+int agx_prof_occupancy(int32_t which, int32_t *blocks_per_cu, int32_t *lds_bytes);
 
 /* ---- dense layers: tf_utils.py:85-88, 132-135 (Dense+ReLU) and their
  *      autodiff (MatMul grads / BiasAddGrad / ReluGrad, tf_utils.py:220,255) -- */
