@@ -38,6 +38,18 @@ __global__ void __launch_bounds__(512) k(float *out, int nm, int nv, int ns, int
   } else if (mode & 4) {
     float *o = out + 1024 + ((size_t)blockIdx.x * 4 + (wave - 4)) * 64 * 64 + lane;
     for (int i = 0; i < ns; ++i) o[(size_t)(i & 63) * 64] = seed + i;
+  } else if (mode & 8) {
+    // dwordx4 loads (1 KiB per wave-instruction) from a 64 KiB window per wave: L2 / L1 hits, 8 in flight
+    const float4 *src = reinterpret_cast<const float4 *>(out + 1024 + ((size_t)blockIdx.x * 4 + (wave - 4)) * 64 * 64) + lane;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < ns; i += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)((i + u) & 63) * 64];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    if (a.x + a.y + a.z + a.w == 12345.678f) out[threadIdx.x] = a.x;
   }
 }
 
@@ -64,6 +76,11 @@ int main() {
   for (int ns : {256, 1024, 4096}) {
     const float ts = run(out, nm, 0, ns, 4), tb = run(out, nm, 0, ns, 5), tm = run(out, nm, 0, 0, 1);
     printf("stores %5d/wave (256 B each): alone %.1f us (%.0f cycles each)  MFMA alone %.1f  both %.1f us  (sum %.1f)\n", ns, ts, ts * 2400.0 / ns, tm, tb, ts + tm);
+  }
+  for (int ns : {256, 1024, 4096}) {
+    const float ts = run(out, nm, 0, ns, 8), tb = run(out, nm, 0, ns, 9), tm = run(out, nm, 0, 0, 1);
+    printf("loads  %5d/wave (dwordx4, 1 KiB each, cache hits): alone %.1f us (%.0f cycles each)  MFMA alone %.1f  both %.1f us  (+%.0f cycles of MFMA time per load)\n", ns, ts,
+           ts * 2400.0 / ns, tm, tb, (tb - tm) * 2400.0 / ns);
   }
   return 0;
 }
