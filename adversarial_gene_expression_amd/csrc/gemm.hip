@@ -1506,6 +1506,13 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   }
   Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk, g->ws ? g->ws_floats : 0,
                       g->ta ? 2 : (g->tb ? 1 : 0));
+  // A fused-optimizer product over a short K (batch < 128) is a memory-bound launch whose epilogue is its long pole:
+  // the 64x64 instantiation (one 32x32 block per wave, operands prefetched, clamp-free interior path) also serves the
+  // shapes whose tile count would choose 128x128 (wide critic, 20007 x 1024 x 96: 123 -> 9x us per launch).  No
+  // split-K either way, so every element keeps the k order of the unfused launch.
+  static const bool opt_small_tiles = getenv("AGX_OPT_BIG_TILES") == nullptr;
+  if (opt && opt_small_tiles && pl.cfg == 0 && pl.splitk == 1 && g->K <= 512 && g->force_cfg < 0)
+    pl = make_plan(g->M, g->N, g->K, 1, 1, g->ws ? g->ws_floats : 0, 2);
   // the fused epilogue exists for the LDS-tiled kernels without split-K; callers ask
   // gemm_can_fuse_opt first, so the product keeps the summation order of the unfused launch
   AGX_CHECK_ARG(!opt || ((pl.cfg == 0 || pl.cfg == 1) && pl.splitk == 1),
