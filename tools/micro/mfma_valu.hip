@@ -38,6 +38,30 @@ __global__ void __launch_bounds__(512) k(float *out, int nm, int nv, int ns, int
   } else if (mode & 4) {
     float *o = out + 1024 + ((size_t)blockIdx.x * 4 + (wave - 4)) * 64 * 64 + lane;
     for (int i = 0; i < ns; ++i) o[(size_t)(i & 63) * 64] = seed + i;
+  } else if (mode & 16) {
+    // LDS traffic: ns ds_write_b32 (one dword per lane) or, with bit 32, ns ds_read_b128 (16 B per lane)
+    __shared__ float4 lds[4][64 * 8];
+    float4 *l = lds[wave - 4];
+    float4 a = {seed, seed, seed, seed};
+    if (mode & 32) {
+      for (int i = 0; i < ns; i += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = l[u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a.x += v[u].x;
+        asm volatile("" ::: "memory");
+      }
+    } else {
+      float *f = reinterpret_cast<float *>(l);
+      for (int i = 0; i < ns; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f[u * 64 + lane] = a.x + (float)u;
+        asm volatile("" ::: "memory");
+      }
+      a.x = f[lane];
+    }
+    if (a.x == 12345.678f) out[threadIdx.x] = a.x;
   } else if (mode & 8) {
     // dwordx4 loads (1 KiB per wave-instruction) from a 64 KiB window per wave: L2 / L1 hits, 8 in flight
     const float4 *src = reinterpret_cast<const float4 *>(out + 1024 + ((size_t)blockIdx.x * 4 + (wave - 4)) * 64 * 64) + lane;
@@ -81,6 +105,14 @@ int main() {
     const float ts = run(out, nm, 0, ns, 8), tb = run(out, nm, 0, ns, 9), tm = run(out, nm, 0, 0, 1);
     printf("loads  %5d/wave (dwordx4, 1 KiB each, cache hits): alone %.1f us (%.0f cycles each)  MFMA alone %.1f  both %.1f us  (+%.0f cycles of MFMA time per load)\n", ns, ts,
            ts * 2400.0 / ns, tm, tb, (tb - tm) * 2400.0 / ns);
+  }
+  for (int ns : {4096, 16384}) {
+    const float ts = run(out, nm, 0, ns, 16), tb = run(out, nm, 0, ns, 17), tm = run(out, nm, 0, 0, 1);
+    printf("ds_write_b32 %5d/wave: alone %.1f us (%.1f cycles each)  MFMA alone %.1f  both %.1f us  (+%.1f cycles of MFMA time each)\n", ns, ts, ts * 2400.0 / ns, tm, tb,
+           (tb - tm) * 2400.0 / ns);
+    const float us = run(out, nm, 0, ns, 48), ub = run(out, nm, 0, ns, 49);
+    printf("ds_read_b128 %5d/wave: alone %.1f us (%.1f cycles each)  MFMA alone %.1f  both %.1f us  (+%.1f cycles of MFMA time each)\n", ns, us, us * 2400.0 / ns, tm, ub,
+           (ub - tm) * 2400.0 / ns);
   }
   return 0;
 }
