@@ -1352,6 +1352,9 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
   pl.wtm = pl.wtn = 1;
   pl.bm = (cfg == 0 || cfg >= 4) ? 128 : (cfg == 1 ? 64 : 32);
   pl.bn = (cfg == 0 || cfg >= 4) ? 128 : (cfg == 1 ? 64 : (cfg == 2 ? 128 : 32));
+  // (a 256x128 tile of 8 waves x 64x64 - a quarter fewer global loads per MFMA - measured 119-124 TF against 115-121 at
+  //  4096^3 and 101 against 104 us on the 512-row first critic layer: not worth six more instantiations;
+  //  profiles/r02_gemm_occupancy_and_ceiling.txt)
   if (cfg >= 20) {
     pl.bm = pl.bn = 128;
   } else if (cfg >= 8) {
