@@ -1017,6 +1017,11 @@ __device__ __forceinline__ int frag_lane_off(int ld, int i, int h) {
 template <bool TA, bool TB, bool VEC, int U, int NW = 4>
 __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
   __shared__ float red[NW][32][33];
+#ifdef AGX_STAMPS
+  long long stamp_v[5] = {0, 0, 0, 0, 0};   // start | first pass multiplied | all passes | stores issued | drained
+  bool first_pass = true;
+#endif
+  AGX_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + 31) / 32;
@@ -1050,6 +1055,12 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
+#ifdef AGX_STAMPS
+      if (first_pass) {
+        AGX_STAMP(1);
+        first_pass = false;
+      }
+#endif
     }
   }
   for (; g0 < ngroups; g0 += NW * U) {
@@ -1066,6 +1077,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
       for (int e = 0; e < 4; ++e)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
   }
+  AGX_STAMP(2);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
   __syncthreads();
@@ -1097,6 +1109,18 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
       }
     }
   }
+#ifdef AGX_STAMPS
+  AGX_STAMP(3);
+  __builtin_amdgcn_s_waitcnt(0);
+  AGX_STAMP(4);
+  if (AGX_STAMP_ON) {
+    long long *o = g_stamps + 8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+    for (int q = 0; q < 5; ++q) o[q] = stamp_v[q];
+    o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    o[7] = (m0 / 32) * 100000 + (n0 / 32) * 100 + z;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1236,7 +1260,9 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
   // long K range per workgroup (the 18k-gene first-layer products at batch 32): 8 waves share it
   static const int nw8_min = getenv("AGX_DIRECT_NW8_MIN") ? atoi(getenv("AGX_DIRECT_NW8_MIN")) : 200;
   if (std::min(p.kchunk, p.K) >= nw8_min) {
-    // (8 k-groups per wave per pass whatever the range - 9, 12 or 18 in flight: +5..9 us per iteration; balancing the passes over the waves - 144 groups as
+    // (8 k-groups per wave per pass whatever the range - 9, 12 or 18 in flight: +5..9 us per iteration.  Re-measured with
+    // phase stamps in round 2: alone, 9 groups save a pass on the 18k-gene products (13.0 -> 11.2 us and 8.4 -> 6.7 us,
+    // tools/stamps_direct.sh), inside the iteration they cost 4 us (0.5222 against 0.5184 ms), 10 groups cost 16 us; balancing the passes over the waves - 144 groups as
     // 3 x 6 per wave instead of 64 + 64 + 16 - measured 5 us per iteration SLOWER; 16 waves: no gain)
     dim3 block8(512, 1, 1);
     static const bool short4 = getenv("AGX_DIRECT8_NO_U4") == nullptr;
