@@ -1262,7 +1262,9 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
   if (std::min(p.kchunk, p.K) >= nw8_min) {
     // (8 k-groups per wave per pass whatever the range - 9, 12 or 18 in flight: +5..9 us per iteration.  Re-measured with
     // phase stamps in round 2: alone, 9 groups save a pass on the 18k-gene products (13.0 -> 11.2 us and 8.4 -> 6.7 us,
-    // tools/stamps_direct.sh), inside the iteration they cost 4 us (0.5222 against 0.5184 ms), 10 groups cost 16 us; balancing the passes over the waves - 144 groups as
+    // tools/stamps_direct.sh), inside the iteration they cost 4 us (0.5222 against 0.5184 ms), 10 groups cost 16 us; 9 only
+    // where that saves a pass: 0.5193 against 0.5148 ms - in the graph a pass is bandwidth-, not latency-bound: the
+    // two longer passes of the first layer take 4.5 + 4.7 us against 4.2 + 5.4 us for the three shorter ones; balancing the passes over the waves - 144 groups as
     // 3 x 6 per wave instead of 64 + 64 + 16 - measured 5 us per iteration SLOWER; 16 waves: no gain)
     dim3 block8(512, 1, 1);
     static const bool short4 = getenv("AGX_DIRECT8_NO_U4") == nullptr;
