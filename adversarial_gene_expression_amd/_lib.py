@@ -135,6 +135,7 @@ class SmallGrads(C.Structure):
         ('l_out', C.c_void_p), ('l_slopes', C.c_void_p),
         ('l_n0', C.c_int32), ('l_n1', C.c_int32), ('l_ns', C.c_int32),
         ('l_inv_b', C.c_float), ('l_gp_weight', C.c_float), ('l_fake_sign', C.c_float),
+        ('l_out_parts', C.c_int32), ('l_out_ld', C.c_int32),
     ]
 
 

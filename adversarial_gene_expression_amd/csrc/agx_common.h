@@ -61,6 +61,11 @@ struct TailArgs {
   float *xcov; int ldx, ncov;
   float coef;
   int rpw;   // rows per workgroup (set by critic_tail)
+  // column split of the hidden Dense over nsplit (1, 2, 4) workgroups per row group (tail.hip): out becomes
+  // out[ns * out_ld + row] partial dot products; A1m = copy of the interpolated rows' A1 (written by mode 0 with
+  // interp_rows > 0, read by mode 1 as the ReLU mask), [interp_rows, lda1]
+  int nsplit, out_ld;
+  float *A1m;
 };
 int critic_tail(void *stream, int mode, const TailArgs &a);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused

@@ -45,7 +45,8 @@ struct agx_cgan {
   float *A[AGX_MAX_LAYERS + 1] = {};        // critic activations  [3Bm, ldh]
   float *D[AGX_MAX_LAYERS + 1] = {};        // critic deltas       [3Bm, ldh]
   int ldh[AGX_MAX_LAYERS + 1] = {};
-  float *out = nullptr, *slopes = nullptr;  // [3Bm], [Bm]
+  float *out = nullptr, *slopes = nullptr;  // [4][3Bm], [Bm]
+  float *A1m = nullptr;                     // [Bm, ldh[1]]
   float *fscale = nullptr, *rowsq = nullptr;  // [Bm], [Bm, nslab]
   int nslab = 0;
   float *gin0 = nullptr;                    // [S*Bm, ldg0] generator layer-1 input [z | num | emb]
@@ -120,7 +121,8 @@ void carve(agx_cgan *h, float *base) {
     h->A[l] = cv.take((int64_t)3 * Bm * h->ldh[l]);
     h->D[l] = cv.take((int64_t)3 * Bm * h->ldh[l]);
   }
-  h->out = cv.take(3 * Bm);
+  h->out = cv.take(4 * 3 * Bm);                      // up to 4 partial dot products per row (column-split tails)
+  h->A1m = cv.take((int64_t)Bm * h->ldh[1]);         // interpolated rows' layer-1 activations: ReLU mask of tail mode 1
   h->slopes = cv.take(Bm);
   h->fscale = cv.take(Bm);
   h->nslab = (c.x_dim + 31) / 32;
@@ -252,10 +254,27 @@ agx::TailArgs tail_args(agx_cgan *h, int splitk, int m_slab) {
   return t;
 }
 
+// column split of a tail launch with `blocks` row groups: few groups leave most CUs idle while every workgroup pulls
+// all of W_2 through one CU (tail.hip)
+int tail_nsplit(int blocks) {
+  static const int force = getenv("AGX_TAIL_NSPLIT") ? atoi(getenv("AGX_TAIL_NSPLIT")) : 0;
+  if (force == 1 || force == 2 || force == 4) return force;
+  return blocks <= 64 ? 4 : (blocks <= 128 ? 2 : 1);
+}
+
+// *out_parts (optional): in = the caller can read the critic output as partial sums, out = how many parts it got
 int tail_forward(agx_cgan *h, hipStream_t st, int splitk, int m_slab, int interp_rows, const float *alpha, int n0,
-                 int n1, float c0, float c1, float c2) {
+                 int n1, float c0, float c1, float c2, int *out_parts = nullptr) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   agx::TailArgs t = tail_args(h, splitk, m_slab);
+  t.A1m = h->A1m;
+  t.out_ld = 3 * h->Bm;
+  t.nsplit = 1;
+  if (out_parts) {
+    const int rpw = (interp_rows == 0 && m_slab <= 64) ? 2 : 4;   // as critic_tail deals the rows
+    t.nsplit = tail_nsplit(interp_rows > 0 ? interp_rows : (m_slab + rpw - 1) / rpw);
+    *out_parts = t.nsplit;
+  }
   t.b1 = h->dp + m.b_off[0]; t.b2 = h->dp + m.b_off[1]; t.w3 = h->dp + m.w_off[2]; t.b3 = h->dp + m.b_off[2];
   t.alpha = alpha; t.interp_rows = interp_rows;
   t.D2 = h->D[2]; t.ldd2 = h->ldh[2]; t.out = h->out;
@@ -266,14 +285,15 @@ int tail_forward(agx_cgan *h, hipStream_t st, int splitk, int m_slab, int interp
 // critic Dense stack from layer index l0 over R rows (input of layer l0 already in place),
 // then Dense(1) + seed of the backward chain D[L] = act'(A_L) * c(r) * w_out
 int disc_layers_from(agx_cgan *h, hipStream_t st, int l0, int R, int n0, int n1, float c0, float c1,
-                     float c2) {
+                     float c2, int *out_parts = nullptr) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   const int L = m.n_layers - 1;
+  if (out_parts) *out_parts = 1;
   if (l0 == 0 && tail_ok(h, R)) {
     int sk = 0;
     Gemm g(h, h->X, h->ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], R, m.dims[1], m.dims[0]);
     AGX_TRY(g.id(AGX_K_DISC_FWD_IN).run_slabs(st, &sk));
-    return tail_forward(h, st, sk, R, 0, nullptr, n0, n1, c0, c1, c2);
+    return tail_forward(h, st, sk, R, 0, nullptr, n0, n1, c0, c1, c2, out_parts);
   }
   for (int l = l0; l < L; ++l) {
     const float *in = l == 0 ? h->X : h->A[l];
@@ -315,13 +335,14 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   const float invb = 1.0f / (float)B_global;
   float *Xi = h->X + (size_t)2 * B * ldx;
   const bool tail = tail_ok(h, B);
+  int out_parts = 1;
   if (tail) {
     // layer-1 slabs of [real; fake]; one launch finishes them (interpolated rows by linearity), runs
     // the second hidden layer and Dense(1) on the 3B rows and seeds the backward chain
     int sk = 0;
     AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], 2 * B, m.dims[1],
                  m.dims[0]).id(AGX_K_DISC_FWD_IN).run_slabs(st, &sk));
-    AGX_TRY(tail_forward(h, st, sk, 2 * B, B, alpha, B, B, -invb, invb, 1.f));
+    AGX_TRY(tail_forward(h, st, sk, 2 * B, B, alpha, B, B, -invb, invb, 1.f, &out_parts));
   } else {
     // layer 1 on [real; fake]; the reduce emits the interpolated rows by linearity (:162-167, :213-214)
     AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], h->ldh[1], 2 * B, m.dims[1],
@@ -349,6 +370,9 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     t.slopes = h->slopes; t.fscale = h->fscale; t.D1 = h->D[1]; t.ldd1 = h->ldh[1];
     t.xcov = Xi + G; t.ldx = ldx; t.ncov = h->ncov;
     t.coef = gp_weight * 2.0f * invb;
+    t.A1m = h->A1m;
+    t.out_ld = 3 * h->Bm;
+    t.nsplit = tail_nsplit((B + (B <= 64 ? 2 : 4) - 1) / (B <= 64 ? 2 : 4));
     AGX_TRY(agx::critic_tail(st, 1, t));
   } else {
   AGX_TRY(agx_gp_finalize(st, h->rowsq, h->nslab, h->nslab, h->slopes, h->fscale, D1i, h->ldh[1],
@@ -415,6 +439,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     j.emb_cat = cat; j.emb_ld_cat = m.emb.n_cat; j.emb_B = B; j.emb_rows = 2 * B;
   }
   j.l_losses = losses; j.l_out = h->out; j.l_slopes = h->slopes; j.l_n0 = B; j.l_n1 = B; j.l_ns = B;
+  j.l_out_parts = out_parts; j.l_out_ld = 3 * h->Bm;
   j.l_inv_b = invb; j.l_gp_weight = gp_weight; j.l_fake_sign = 1.f;
   AGX_TRY(agx::small_grads_run(st, &j, agx::LossCopy{nullptr, nullptr, 0}, &tn));
   if (dw1_last) AGX_TRY(weight_grad(0));
@@ -430,7 +455,8 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   const float invb = 1.0f / (float)B_global;
   float *dX = h->X + (size_t)B * ldx;
   // critic forward (:250) + seed -1/B of d mean(-D)/d out; critic weights untouched   :255
-  AGX_TRY(disc_layers_from(h, st, 0, B, B, 0, -invb, 0.f, 0.f));
+  int out_parts = 1;
+  AGX_TRY(disc_layers_from(h, st, 0, B, B, 0, -invb, 0.f, 0.f, &out_parts));
   AGX_TRY(disc_backward_chain(h, st, B));
   AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1])
               .id(AGX_K_DISC_DX).run(st));
@@ -481,6 +507,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     j.emb_cat = cat; j.emb_ld_cat = gm.emb.n_cat; j.emb_B = B; j.emb_rows = B;
   }
   j.l_losses = losses; j.l_out = h->out; j.l_n0 = B; j.l_n1 = 0; j.l_ns = 0;   // mean(-D(fake))  :253
+  j.l_out_parts = out_parts; j.l_out_ld = 3 * h->Bm;
   j.l_inv_b = invb; j.l_gp_weight = 0.f; j.l_fake_sign = 1.f;
   AGX_TRY(agx::small_grads_run(st, &j, lc ? *lc : agx::LossCopy{nullptr, nullptr, 0}, &tn));
   if (fo && fo->rest_n > 0) {

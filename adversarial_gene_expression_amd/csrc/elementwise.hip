@@ -832,8 +832,14 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
   }
   if (j.l_losses && blk == 0) {
     float sr = 0.f, sf = 0.f, sg = 0.f;
-    for (int i = threadIdx.x; i < j.l_n0; i += blockDim.x) sr += j.l_out[i];
-    for (int i = threadIdx.x; i < j.l_n1; i += blockDim.x) sf += j.l_out[j.l_n0 + i];
+    // critic output of row i: l_out_parts partial dot products (column-split tail launches), added in part order
+    auto outv = [&](int i) {
+      float v = j.l_out[i];
+      for (int s = 1; s < j.l_out_parts; ++s) v += j.l_out[(size_t)s * j.l_out_ld + i];
+      return v;
+    };
+    for (int i = threadIdx.x; i < j.l_n0; i += blockDim.x) sr += outv(i);
+    for (int i = threadIdx.x; i < j.l_n1; i += blockDim.x) sf += outv(j.l_n0 + i);
     for (int i = threadIdx.x; i < j.l_ns; i += blockDim.x) {
       const float d = j.l_slopes[i] - 1.f;
       sg += d * d;

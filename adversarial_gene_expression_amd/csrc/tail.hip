@@ -12,6 +12,14 @@
 //
 // fp32 VALU (4 rows x 256 x 256 MACs per workgroup: nothing for MFMA to win); fixed summation
 // orders (deterministic).
+//
+// NS > 1 (few row groups, i.e. small batches): the hidden Dense of a row group is split by output columns over NS
+// workgroups (blockIdx.y).  A workgroup pulling all of W2 (256 KB) is bound by its CU's 64 B/clk (1.7 us) and by four
+// dependent batches of 16 loads; a quarter of the columns is 64 KB in ONE batch.  Every workgroup of the group repeats
+// the cheap part (slab sums -> A1 / E1 in LDS); only workgroup 0 writes the shared results.  The row's critic output
+// then arrives as NS partial dot products out[ns][row] (bias in part 0) that the loss job adds in order.  Mode 1
+// overwrites A1 (whose sign is the ReLU mask it needs) in place: with NS > 1 it reads the mask from a copy of the
+// interpolated rows' A1 that mode 0 leaves in A1m, so that workgroup 0's store cannot race the others' loads.
 #include "agx_common.h"
 
 #include <algorithm>
@@ -24,13 +32,17 @@ using agx::wave_sum;
 constexpr int TW = 256;  // max hidden width
 constexpr int TR = 4;    // rows per workgroup
 
-template <int MODE>
+template <int MODE, int NS>
 __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p) {
+  constexpr int HC = TW / NS;      // output columns of the hidden Dense per workgroup
+  constexpr int KQ = 4 * NS;       // thread groups over k in the Dense loop (1024 threads = KQ x HC)
   __shared__ float raw[TR][TW];
   __shared__ float4 a1[TW];   // [k] -> the four rows' values: one ds_read_b128 per k in the Dense loop
-  __shared__ float part[4][TR][TW];
+  __shared__ float part[KQ * TR * HC];   // [q][row][column]: 4096 floats whatever NS
   __shared__ float red[16];
   const int t = threadIdx.x, i = t >> 8, c = t & 255, lane = t & 63, wave = t >> 6;
+  const int ns = NS > 1 ? (int)blockIdx.y : 0;
+  const bool lead = ns == 0;       // the workgroup that writes what the column groups share
   const bool interp = MODE == 0 && p.interp_rows > 0;
   const int R = p.interp_rows;
   // slab rows / output rows of this workgroup
@@ -53,7 +65,7 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
     __syncthreads();
     const float sl = sqrtf(red[4 * i] + red[4 * i + 1] + red[4 * i + 2] + red[4 * i + 3]);
     f = p.coef * (sl - 1.f) / sl;  // sl == 0 -> NaN propagates like the reference
-    if (i < nsl && c == 0) {
+    if (lead && i < nsl && c == 0) {
       p.slopes[srow(i)] = sl;
       p.fscale[srow(i)] = f;
     }
@@ -104,7 +116,10 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
       }
       x += p.b1[c];
       a = x > 0.f ? x : x * p.slope;
-      p.A1[(size_t)orow(i) * p.lda1 + c] = a;
+      if (lead) {
+        p.A1[(size_t)orow(i) * p.lda1 + c] = a;
+        if (interp && i == 2 && p.A1m) p.A1m[(size_t)r0 * p.lda1 + c] = a;   // mask copy for a column-split mode 1
+      }
     }
     reinterpret_cast<float *>(&a1[c])[i] = a;
   } else {
@@ -112,22 +127,25 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
     if (i < nsl && c < p.H1) {
       const size_t o = (size_t)orow(i) * p.lda1 + c;
       const float x = v * f;
-      e = p.A1[o] > 0.f ? x : x * p.slope;
-      p.A1[o] = e;
-      float *d = p.D1 + (size_t)orow(i) * p.ldd1 + c;
-      *d = *d * f;
+      const float mk = (NS > 1) ? p.A1m[(size_t)srow(i) * p.lda1 + c] : p.A1[o];
+      e = mk > 0.f ? x : x * p.slope;
+      if (lead) {
+        p.A1[o] = e;
+        float *d = p.D1 + (size_t)orow(i) * p.ldd1 + c;
+        *d = *d * f;
+      }
     }
-    if (i < nsl && c < p.ncov) p.xcov[(size_t)srow(i) * p.ldx + c] = 0.f;
+    if (lead && i < nsl && c < p.ncov) p.xcov[(size_t)srow(i) * p.ldx + c] = 0.f;
     reinterpret_cast<float *>(&a1[c])[i] = e;
   }
   __syncthreads();
 
   // ---- hidden Dense: k split over the four 256-thread groups, W2 rows read coalesced, once
   {
-    const int j = c, q = i;
+    const int jl = t % HC, q = t / HC, j = ns * HC + jl;
     float acc[TR] = {0.f, 0.f, 0.f, 0.f};
     if (j < p.H2) {
-      const int kq = (p.H1 + 3) >> 2;
+      const int kq = (p.H1 + KQ - 1) / KQ;
       const int k0 = q * kq, k1 = min(p.H1, k0 + kq);
       const float *__restrict__ w = p.W2 + (size_t)k0 * p.ldw2 + j;
       int k = k0;
@@ -159,12 +177,18 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
       }
     }
 #pragma unroll
-    for (int r = 0; r < TR; ++r) part[q][r][j] = acc[r];
+    for (int r = 0; r < TR; ++r) part[(q * TR + r) * HC + jl] = acc[r];
   }
   __syncthreads();
+  // finish: thread (row fi, column fl of this workgroup's HC columns); NS = 1 is the old (i, c) numbering and order
+  const int fi = t / HC, fl = t % HC, fc = ns * HC + fl;
   float hp = 0.f;
-  if (i < nout && c < p.H2) {
-    float x = (part[0][i][c] + part[1][i][c]) + (part[2][i][c] + part[3][i][c]);
+  if (t < TR * HC && fi < nout && fc < p.H2) {
+    auto pq = [&](int q) { return part[(q * TR + fi) * HC + fl]; };
+    float x = (pq(0) + pq(1)) + (pq(2) + pq(3));
+#pragma unroll
+    for (int q = 4; q < KQ; q += 4) x += (pq(q) + pq(q + 1)) + (pq(q + 2) + pq(q + 3));
+    const int i = fi, c = fc;
     const size_t o = (size_t)orow(i) * p.lda2 + c;
     if (MODE == 0) {
       x += p.b2[c];
@@ -183,7 +207,15 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
     hp = wave_sum(hp);
     if (lane == 0) red[wave] = hp;
     __syncthreads();
-    if (i < nout && c == 0) p.out[orow(i)] = (red[4 * i] + red[4 * i + 1]) + (red[4 * i + 2] + red[4 * i + 3]) + p.b3[0];
+    if (NS == 1) {
+      if (i < nout && c == 0) p.out[orow(i)] = (red[4 * i] + red[4 * i + 1]) + (red[4 * i + 2] + red[4 * i + 3]) + p.b3[0];
+    } else if (t < TR * HC && fi < nout && fl == 0) {
+      constexpr int WR = HC / 64;   // waves per row
+      float s = red[fi * WR];
+#pragma unroll
+      for (int w = 1; w < WR; ++w) s += red[fi * WR + w];
+      p.out[(size_t)ns * p.out_ld + orow(fi)] = lead ? s + p.b3[0] : s;
+    }
   }
 }
 
@@ -194,6 +226,8 @@ int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
   AGX_CHECK_ARG(a.ws && a.splitk >= 1 && a.m_slab >= 1 && a.H1 >= 1 && a.H1 <= TW && a.H2 >= 1 && a.H2 <= TW &&
                     a.W2 && a.ldw2 >= a.H2 && a.A1 && a.A2 && a.lda1 >= a.H1 && a.lda2 >= a.H2,
                 "critic_tail: bad shapes (H1=%d H2=%d m=%d)", a.H1, a.H2, a.m_slab);
+  AGX_CHECK_ARG(a.nsplit == 0 || a.nsplit == 1 || ((a.nsplit == 2 || a.nsplit == 4) && a.out_ld > 0 && (mode == 0 || a.A1m)),
+                "critic_tail: column split %d needs out_ld and the mask copy", a.nsplit);
   hipStream_t st = agx::as_stream(stream);
   // rows per workgroup: every workgroup pulls all of W2 (256 KB at 64 B/clk: 1.7 us) whatever its row count, so
   // few rows are spread over more CUs (their slab traffic per CU shrinks); many rows keep 4 per workgroup
@@ -206,14 +240,19 @@ int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
     agx::ProfScope prof(st, AGX_K_DISC_FWD_HID, 2.0 * (a.interp_rows ? 3 * a.interp_rows : a.m_slab) * a.H1 * (double)a.H2,
                         4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));
     const int blocks = a.interp_rows > 0 ? a.interp_rows : agx::cdiv(a.m_slab, a.rpw);
-    hipLaunchKernelGGL(critic_tail_kernel<0>, dim3(blocks), dim3(1024), 0, st, a);
+    if (a.nsplit == 4) hipLaunchKernelGGL((critic_tail_kernel<0, 4>), dim3(blocks, 4), dim3(1024), 0, st, a);
+    else if (a.nsplit == 2) hipLaunchKernelGGL((critic_tail_kernel<0, 2>), dim3(blocks, 2), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((critic_tail_kernel<0, 1>), dim3(blocks), dim3(1024), 0, st, a);
   } else {
     AGX_CHECK_ARG(a.rowsq && a.slopes && a.fscale && a.D1 && a.ldd1 >= a.H1 && a.nslab >= 1 && a.rowsq_ld >= a.nslab &&
                       a.ncov >= 0 && a.ncov <= 256 && (a.ncov == 0 || a.xcov),
                   "critic_tail: second-order arguments");
     agx::ProfScope prof(st, AGX_K_GP2_HID, 2.0 * a.m_slab * a.H1 * (double)a.H2,
                         4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));
-    hipLaunchKernelGGL(critic_tail_kernel<1>, dim3(agx::cdiv(a.m_slab, a.rpw)), dim3(1024), 0, st, a);
+    const int blocks = agx::cdiv(a.m_slab, a.rpw);
+    if (a.nsplit == 4) hipLaunchKernelGGL((critic_tail_kernel<1, 4>), dim3(blocks, 4), dim3(1024), 0, st, a);
+    else if (a.nsplit == 2) hipLaunchKernelGGL((critic_tail_kernel<1, 2>), dim3(blocks, 2), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((critic_tail_kernel<1, 1>), dim3(blocks), dim3(1024), 0, st, a);
   }
   AGX_LAUNCH_CHECK();
   return AGX_OK;

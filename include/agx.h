@@ -238,6 +238,9 @@ typedef struct agx_small_grads {
   const float *l_out, *l_slopes;
   int32_t l_n0, l_n1, l_ns;
   float l_inv_b, l_gp_weight, l_fake_sign;
+  /* the critic output of row i may arrive as l_out_parts (0 or 1: a plain vector) partial sums
+   * l_out[s * l_out_ld + i], added in part order (column-split critic tail launches) */
+  int32_t l_out_parts, l_out_ld;
 } agx_small_grads_t;
 int agx_small_grads(void *stream, const agx_small_grads_t *jobs);
 
