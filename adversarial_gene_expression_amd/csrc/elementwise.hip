@@ -656,51 +656,50 @@ __device__ __forceinline__ void emb_dots(const agx_small_grads_t &j, int i, int 
   }
 }
 
-__global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads_t j, const agx::LossCopy lc,
-                                                           const agx::TnJobs tn) {
+// Which job a workgroup runs is decided on the HOST: segment s covers blocks [start[s], start[s+1]) and is job
+// (kind, idx).  The kernel used to walk the job lists itself - a chain of ~8 dependent scalar loads from the 1 KB
+// argument block with a branch after each - and every workgroup spent 2.2 us of a 7.7 us launch there before its
+// job began (phase stamps).  Now: the start table in one go, a branch-free count, one more load.
+// Segments are ordered longest job first (embedding rows, products, loss, weighted and plain column sums) so that
+// a launch of more workgroups than CUs (the generator step: 333) does not start its long pole in the second round.
+struct SmallPlan {
+  int n_seg;
+  int start[37];   // start[n_seg] = number of blocks
+  signed char kind[36], idx[36];   // kind: 0 product, 1 column sum, 2 weighted column sum, 3 embedding table, 4 loss
+  short coff[36];  // embedding table idx: its first kernel row
+};
+
+__global__ void __launch_bounds__(1024) small_grads_kernel(const SmallPlan plan, const agx_small_grads_t j,
+                                                           const agx::LossCopy lc, const agx::TnJobs tn) {
   __shared__ float red[16][64];
   __shared__ __attribute__((aligned(16))) float svec[8192];   // [0,6144): partial / final column sums, [6144,8192): row match flags
   __shared__ int elist[2048];   // matching rows of an embedding-table row (many-row path)
   __shared__ int wcnt[16];
-  int blk = blockIdx.x;
-  // blocks in front: the tiny weight-gradient products, 4 tiles per block - one wave per SIMD (16 tiles
-  // on one CU queue 4 waves' MFMAs per SIMD: the launch grew from 8.5 to 13 us); waves 4..15 leave
-  for (int q = 0; q < tn.n; ++q) {
-    const int nb = (((tn.job[q].M + 31) / 32) * ((tn.job[q].N + 31) / 32) + 3) / 4;
-    if (blk < nb) {
-      if (threadIdx.x < 256) tn_wave_tile(tn.job[q], blk * 4 + (int)(threadIdx.x >> 6));
-      return;
-    }
-    blk -= nb;
+  int seg = 0;
+#pragma unroll
+  for (int s = 1; s < 36; ++s) seg += (s < plan.n_seg && (int)blockIdx.x >= plan.start[s]) ? 1 : 0;
+  const int kind = plan.kind[seg], jidx = plan.idx[seg];
+  int blk = (int)blockIdx.x - plan.start[seg];
+  if (kind == 0) {
+    // the tiny weight-gradient products, 4 tiles per block - one wave per SIMD (16 tiles
+    // on one CU queue 4 waves' MFMAs per SIMD: the launch grew from 8.5 to 13 us); waves 4..15 leave
+    if (threadIdx.x < 256) tn_wave_tile(tn.job[jidx], blk * 4 + (int)(threadIdx.x >> 6));
+    return;
   }
-  for (int c = 0; c < j.n_colsum; ++c) {
-    const int nb = (j.cs_H[c] + 63) / 64;
-    if (blk < nb) {
-      colsum_block(j.cs_A[c], j.cs_lda[c], j.cs_r0[c], j.cs_r1[c], j.cs_H[c], j.cs_out[c], blk, 0, 0, 0,
-                   0.f, 0.f, 0.f, nullptr, red, svec);
-      return;
-    }
-    blk -= nb;
+  if (kind == 1) {
+    const int c = jidx;
+    colsum_block(j.cs_A[c], j.cs_lda[c], j.cs_r0[c], j.cs_r1[c], j.cs_H[c], j.cs_out[c], blk, 0, 0, 0,
+                 0.f, 0.f, 0.f, nullptr, red, svec);
+    return;
   }
-  if (j.w_A) {
-    const int nb = (j.w_H + 63) / 64;
-    if (blk < nb) {
-      colsum_block(j.w_A, j.w_lda, 0, j.w_R, j.w_H, j.w_out, blk, 1, j.w_n0, j.w_n1, j.w_c0, j.w_c1,
-                   j.w_c2, j.w_bias_out, red, svec);
-      return;
-    }
-    blk -= nb;
+  if (kind == 2) {
+    colsum_block(j.w_A, j.w_lda, 0, j.w_R, j.w_H, j.w_out, blk, 1, j.w_n0, j.w_n1, j.w_c0, j.w_c1,
+                 j.w_c2, j.w_bias_out, red, svec);
+    return;
   }
-  if (j.emb_grad) {
-    int rows = 0;
-    for (int i = 0; i < j.emb.n_cat; ++i) rows += j.emb.vocab[i];
-    if (blk < rows) {
-      int rowid = blk, i = 0, coff = j.emb_col0;
-      while (rowid >= j.emb.vocab[i]) {
-        rowid -= j.emb.vocab[i];
-        coff += j.emb.edim[i];
-        ++i;
-      }
+  if (kind == 3) {
+    {
+      const int rowid = blk, i = jidx, coff = plan.coff[seg];
       const int H = j.emb_H;
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       float *part = svec, *sfin = H <= 512 ? svec + 1024 : svec;
@@ -828,9 +827,8 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const agx_small_grads
       emb_dots(j, i, rowid, coff, sfin, H);
       return;
     }
-    blk -= rows;
   }
-  if (j.l_losses && blk == 0) {
+  if (kind == 4) {
     float sr = 0.f, sf = 0.f, sg = 0.f;
     // critic output of row i: l_out_parts partial dot products (column-split tail launches), added in part order
     auto outv = [&](int i) {
@@ -1275,7 +1273,35 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
   }
   if (blocks == 0) return AGX_OK;
   AGX_CHECK_ARG(!lc.dst_slot || (j->l_losses && lc.src && lc.n >= 0), "agx_small_grads: loss snapshot without a loss job");
-  hipLaunchKernelGGL(small_grads_kernel, dim3(blocks), dim3(1024), 0, agx::as_stream(stream), *j, lc, tj);
+  // block -> job plan, longest jobs first (see SmallPlan)
+  SmallPlan plan = {};
+  int nseg = 0, at = 0;
+  auto seg = [&](int kind, int idx, int coff, int nb) {
+    if (nb <= 0) return;
+    plan.start[nseg] = at;
+    plan.kind[nseg] = (signed char)kind;
+    plan.idx[nseg] = (signed char)idx;
+    plan.coff[nseg] = (short)coff;
+    ++nseg;
+    at += nb;
+  };
+  static_assert(2 * AGX_MAX_LAYERS + AGX_MAX_CAT + 2 <= 36, "SmallPlan segment table too small");
+  if (j->emb_grad) {
+    int coff = j->emb_col0;
+    for (int i = 0; i < j->emb.n_cat; ++i) {
+      AGX_CHECK_ARG(coff <= 32767, "agx_small_grads: embedding kernel row %d beyond the plan's range", coff);
+      seg(3, i, coff, j->emb.vocab[i]);
+      coff += j->emb.edim[i];
+    }
+  }
+  for (int q = 0; q < tj.n; ++q) seg(0, q, 0, agx::cdiv(agx::cdiv(tj.job[q].M, 32) * agx::cdiv(tj.job[q].N, 32), 4));
+  if (j->l_losses) seg(4, 0, 0, 1);
+  if (j->w_A) seg(2, 0, 0, agx::cdiv(j->w_H, 64));
+  for (int c = 0; c < j->n_colsum; ++c) seg(1, c, 0, agx::cdiv(j->cs_H[c], 64));
+  plan.n_seg = nseg;
+  plan.start[nseg] = at;
+  AGX_CHECK_ARG(at == blocks, "agx_small_grads: plan covers %d of %d blocks", at, blocks);
+  hipLaunchKernelGGL(small_grads_kernel, dim3(blocks), dim3(1024), 0, agx::as_stream(stream), plan, *j, lc, tj);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
