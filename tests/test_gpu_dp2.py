@@ -5,7 +5,8 @@ distributed paths with the real HIP kernels:
   * gamma_coef / GammaScorer: the upper-triangular tile list dealt over the ranks + one 6-scalar
     all-reduce, including the NaN fall-back (reference utils.py:863-873, :844-849);
   * make_score_fn: generator forward over row shards of the test set + all-gather.
-RCCL itself cannot be exercised on a one-GPU box; the collectives here are gloo's."""
+A one-GPU box cannot run two RCCL ranks: the two-rank collectives here are gloo's; the last test drives the same
+wrappers through RCCL (c10d's communicator and libagx's own) with a single rank."""
 import os
 import socket
 import sys
@@ -125,3 +126,45 @@ def test_two_ranks_reproduce_the_one_process_run(gpu, tmp_path):
     yc[:, 7] = 2.0
     with np.errstate(all='ignore'):
         assert abs(float(ref['gamma_nan'][0]) - float(CO.gamma_coef(xc, yc))) < 2e-5
+
+
+def _rccl_worker(rank, port, out_path, native):
+    """One rank over the 'nccl' (= RCCL) backend, initialised as bench.py does it: the collectives wrappers of the
+    data-parallel step on device tensors.  With one rank every collective is the identity, but the call goes
+    through c10d's RCCL communicator (or libagx's own with AGX_NATIVE_COMM=1) on the compute stream."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if native:
+        os.environ['AGX_NATIVE_COMM'] = '1'
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from adversarial_gene_expression_amd import _dev
+        src = torch.arange(4096, dtype=torch.float32, device='cuda') * 0.25 - 7.0
+        a = src.clone()
+        _dev.allreduce_sum(a)
+        rs = torch.zeros(4096, dtype=torch.float32, device='cuda')
+        _dev.reduce_scatter_sum(rs, src)
+        ag = torch.zeros(4096, dtype=torch.float32, device='cuda')
+        _dev.all_gather(ag, src)
+        d = torch.tensor([1.5, -2.0, 3.25, 0.0, 1e300, -1e-300], dtype=torch.float64, device='cuda')
+        d2 = d.clone()
+        _dev.allreduce_sum(d2)
+        torch.cuda.synchronize()
+        np.savez(out_path, src=src.cpu().numpy(), a=a.cpu().numpy(), rs=rs.cpu().numpy(), ag=ag.cpu().numpy(),
+                 d=d.cpu().numpy(), d2=d2.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('native', [False, True], ids=['c10d', 'agx_comm'])
+def test_collectives_run_through_rccl_with_one_rank(gpu, tmp_path, native):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'rccl.npz')
+    mp.spawn(_rccl_worker, args=(_free_port(), out, native), nprocs=1, join=True)
+    r = np.load(out)
+    for k in ('a', 'rs', 'ag'):
+        np.testing.assert_array_equal(r[k], r['src'])
+    np.testing.assert_array_equal(r['d2'], r['d'])
