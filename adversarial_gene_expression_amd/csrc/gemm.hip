@@ -591,6 +591,8 @@ gemm_kernel(const KParams p) {
   };
   // (requesting the first two K-tiles BEFORE these operands - vmcnt retires in issue order - measured slower:
   // 0.532 against 0.522 ms per 32-row iteration; so did moving them as dwordx4 through an LDS transposition)
+  // (non-temporal loads and stores of the optimizer slots: 0.4947 against 0.4921 ms; of the weights too: 0.5034 -
+  // both matrices are re-read from cache by the next step's launches)
   opt_prefetch();
 
   float4 ra[TileA::PT], rb[TileB::PT];
