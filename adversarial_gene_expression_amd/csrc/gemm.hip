@@ -1385,6 +1385,10 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
   // (a 256x128 tile of 8 waves x 64x64 - a quarter fewer global loads per MFMA - measured 119-124 TF against 115-121 at
   //  4096^3 and 101 against 104 us on the 512-row first critic layer: not worth six more instantiations;
   //  profiles/r02_gemm_occupancy_and_ceiling.txt)
+  // (160x128 / 128x160 tiles of 4 waves x five 32x32 blocks - 18161 = 113.5 x 160, so the 18k-gene dimension times 256
+  //  or 512 makes 228 / 456 tiles = one round - measured 169.8 against 173.6 us on the 512-row dW_1 (one workgroup per
+  //  CU has nothing to overlap with), 63.0 against 58.8 us on the input gradient, 347 against 327 us on the generator
+  //  output layer; 230-256 registers with spills in four layouts: profiles/r02_tile160.txt)
   if (cfg >= 20) {
     pl.bm = pl.bn = 128;
   } else if (cfg >= 8) {
