@@ -149,6 +149,8 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
       const int k0 = q * kq, k1 = min(p.H1, k0 + kq);
       const float *__restrict__ w = p.W2 + (size_t)k0 * p.ldw2 + j;
       int k = k0;
+      // (the first batch requested at kernel start, in front of or right behind the slab loads, so that the two
+      // round trips overlap: 0.4957 against 0.4925 ms per 32-row iteration, 2.711 against 2.696 ms at 512 rows)
       // 16 weight loads in flight per thread: the k loop is a chain of L2 round trips, not arithmetic
       // (batches of 8 took 8 round trips per quarter of a 256-wide layer; batches of 32 gain nothing at 32 rows
       // and lose 0.5 % at 512, batches of 64 lose 6 %)
