@@ -1016,9 +1016,32 @@ __device__ __forceinline__ int frag_lane_off(int ld, int i, int h) {
 }
 
 // NW = 8 (long K ranges): two waves per SIMD, so one wave's loads are in flight while the other's MFMAs issue
+// STAGED B operand (8-wave instantiations, 16-B aligned operands): the streamed weight matrix is not loaded in MFMA
+// fragment order - k-contiguous (NT): lane (row, half) takes 16 B of its row per instruction, so one instruction
+// touches 32 lines for 32 B each and every line is requested by four instructions; row-contiguous (NN): four dword
+// loads per 8-k group - but in LINE order (float4, one instruction = eight whole 128-B lines: the wave's 8U k of 32
+// rows in U instructions) and turned into fragments through a wave-private LDS block in the k-quad image of the tiled
+// kernel (no workgroup barrier: a wave's LDS instructions execute in order).  Same values in the same lanes, so the
+// product is bit-identical.  One pass over W_1 out of the Infinity Cache: 3.9 us in fragment order, 2.45 us in line
+// order (tools/micro/stream_patterns.hip; L2 keeps nothing across launches: FETCH_SIZE = the whole matrix on every
+// launch).  Measured (profiles/r02_direct_kernel_staging.txt): 64x256x18161 14.9 -> 14.0 us, 1024x256x18161 136 ->
+// 119 us, 32x20000x1024 NT 30.4 -> 26.4 us, 32-row iteration 0.4956 -> 0.4887 ms.  Staging the A operand the same way
+// (bit 2) loses: 16.2 us and 0.530 ms - its re-reads hit L2, the extra LDS hop only adds latency to every pass.
+// AGX_DIRECT_STAGE bits: 1 = B of NT, 4 = B of NN, 2 = A (k-contiguous)
+#ifndef AGX_DIRECT_STAGE
+#define AGX_DIRECT_STAGE 5
+#endif
 template <bool TA, bool TB, bool VEC, int U, int NW = 4>
 __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
-  __shared__ float red[NW][32][33];
+  constexpr bool STAGE_B = NW == 8 && VEC && (TB ? (AGX_DIRECT_STAGE & 1) != 0 : (AGX_DIRECT_STAGE & 4) != 0);
+  // both operands only while the two blocks of the 8 waves fit the 64 KB of static LDS (U = 4)
+  constexpr bool STAGE_A = (AGX_DIRECT_STAGE & 2) && NW == 8 && VEC && !TA && (!STAGE_B || U <= 4);
+  constexpr int NSTG = (STAGE_A ? 1 : 0) + (STAGE_B ? 1 : 0);
+  using WT = Tile<32, true, 64, true, 8 * U>;   // one wave's block: 32 rows x 8U k, PT = U float4 per lane
+  using WTB = Tile<32, TB, 64, true, 8 * U>;    // B: k-contiguous (NT) or row-contiguous (NN: 8 k-rows x 128 B per instruction)
+  constexpr int SM_RED = NW * 32 * 33, SM_STG = NW * NSTG * WT::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem_d[SM_RED > SM_STG ? SM_RED : SM_STG];
+  float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(smem_d);   // (after the passes: the staging blocks are dead)
 #ifdef AGX_STAMPS
   long long stamp_v[5] = {0, 0, 0, 0, 0};   // start | first pass multiplied | all passes | stores issued | drained
   bool first_pass = true;
@@ -1044,13 +1067,42 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
   if (m0 + 32 <= p.M && n0 + 32 <= p.N) {  // interior tile: full k-groups without clamps or masks
     const int nfull = (kend - kbeg) / 8;
     const int la = frag_lane_off<!TA>(p.lda, i, h), lb = frag_lane_off<TB>(p.ldb, i, h);
+    int offa[WT::PT], offb[WT::PT];
+    if (STAGE_A) WT::lane_offsets(p.lda, lane, offa);
+    if (STAGE_B) WTB::lane_offsets(p.ldb, lane, offb);
+    float *stg_a = smem_d + wave * NSTG * WT::LDS_FLOATS;
+    float *stg_b = stg_a + (STAGE_A ? WT::LDS_FLOATS : 0);
     for (; g0 + U <= nfull; g0 += NW * U) {
       float av[U][4], bv[U][4];
+      float4 ra[WT::PT], rb[WT::PT];
+      if (STAGE_A) WT::load_fast(WT::ubase(p.A, p.lda, m0, kbeg + 8 * g0), offa, ra);
+      if (STAGE_B) WTB::load_fast(WTB::ubase(p.B, p.ldb, n0, kbeg + 8 * g0), offb, rb);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = kbeg + 8 * (g0 + u);
-        frag_fast4<!TA, VEC>(frag_ubase<!TA>(p.A, p.lda, m0, k), la, p.lda, av[u]);
-        frag_fast4<TB, VEC>(frag_ubase<TB>(p.B, p.ldb, n0, k), lb, p.ldb, bv[u]);
+        if (!STAGE_A) frag_fast4<!TA, VEC>(frag_ubase<!TA>(p.A, p.lda, m0, k), la, p.lda, av[u]);
+        if (!STAGE_B) frag_fast4<TB, VEC>(frag_ubase<TB>(p.B, p.ldb, n0, k), lb, p.ldb, bv[u]);
+      }
+      if (NSTG > 0) {
+        // (the previous pass's fragment reads precede these writes in program order: in-order LDS, same wave)
+        if (STAGE_A) WT::store_fast(stg_a, lane, ra);
+        if (STAGE_B) WTB::store_fast(stg_b, lane, rb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (STAGE_A) {
+            const float4 q = WT::frag4(stg_a, i, u, h);
+            av[u][0] = q.x; av[u][1] = q.y; av[u][2] = q.z; av[u][3] = q.w;
+          }
+          if (STAGE_B) {
+            const float4 q = WTB::frag4(stg_b, i, u, h);
+            bv[u][0] = q.x; bv[u][1] = q.y; bv[u][2] = q.z; bv[u][3] = q.w;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -1080,6 +1132,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
   }
   AGX_STAMP(2);
+  if (NSTG > 0) __syncthreads();   // the partial sums below overwrite other waves' staging blocks
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
   __syncthreads();

@@ -105,6 +105,11 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True)
     p_aug = P_AUG.get(workload, 0)
     np.random.seed(0)      # augmentation constants (NumPy draws at first use, like the reference's trace constants)
     last = [None]
+    walk = [0]             # every iteration, probe or timed, takes the NEXT batch of the pool (see the note at the warm-up)
+
+    def next_i():
+        walk[0] += 1
+        return walk[0] - 1
 
     def iteration(i):
         s = slice((i % nbatches) * B, (i % nbatches + 1) * B)
@@ -150,14 +155,14 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True)
         for i in range(n):
             if world == 1:
                 _lib.check(lib.agx_prof_spin(torch.cuda.current_stream().cuda_stream, 4000 if B <= 64 else 1000))
-            eager_iteration(i)
+            eager_iteration(next_i())
         torch.cuda.synchronize()
         lib.agx_prof_enable(-2)
         return prof_read_all(lib, _lib)
 
     dbg = (lambda m: print('[bench rank %d] %s' % (rank, m), file=sys.stderr, flush=True)) if os.environ.get('AGX_BENCH_DEBUG') else (lambda m: None)
     dbg('models built')
-    iteration(0)                               # first call: workspace, graph capture
+    iteration(next_i())                        # first call: workspace, graph capture
     sync()
     nprobe = 3
     if roofline:
@@ -167,18 +172,18 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True)
     lib.agx_prof_reset()
     # the W untimed warm-up steps run right in front of the timed region (the probe above leaves the
     # GPU idle between its bracketed launches; 3 % slower steps were measured straight after it)
-    # (batches are walked in sequence 1, 2, ... across warm-up and timed region, as train() walks the data set:
+    # (batches are walked in sequence across probe, warm-up and timed region, as train() walks the data set:
     #  training twice in a row on one batch of this synthetic data drives the wide critic to a zero penalty slope,
     #  whose NaN - tf_utils.py:169 has no epsilon - the fp64 oracle reproduces at the same step:
     #  profiles/r02_wide_zero_slope_nan_matches_oracle.txt)
     for i in range(warmup):
-        iteration(1 + i)
+        iteration(next_i())
         dbg('warmup %d queued' % i)
     sync()
     dbg('warmup done')
     t0 = time.perf_counter()
     for i in range(steps):
-        iteration(1 + warmup + i)
+        iteration(next_i())
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -341,6 +341,75 @@ def test_small_grads_matches_separate_entry_points(gpu, B, H):
     np.testing.assert_allclose(ls[:3], [w, gp, w + 10 * gp], rtol=1e-5, atol=1e-5)
 
 
+def test_small_grads_with_the_maximum_number_of_jobs(gpu):
+    """AGX_MAX_CAT embedding tables + AGX_MAX_LAYERS column sums + the weighted sum + the loss job in one launch:
+    the host-computed block -> job segment table at its largest (elementwise.hip SmallPlan)."""
+    _dev, _lib, lib = _libs()
+    from adversarial_gene_expression_amd._dev import ptr
+    rs = np.random.RandomState(77)
+    B, H, NL, NC = 9, 72, 8, 16
+    R = 3 * B
+    vocab = [int(v) for v in rs.randint(1, 9, NC)]
+    edim = [int(v) for v in rs.randint(1, 5, NC)]
+    offs, o = [], 0
+    for v, dd in zip(vocab, edim):
+        offs.append(o)
+        o += v * dd + 3                       # 3 floats of padding between tables
+    e = _embed_desc(_lib, vocab, edim, offs)
+    col0 = 5
+    nin = col0 + sum(edim)
+    D1 = rs.randn(R, H).astype(np.float32)
+    W = rs.randn(nin, H).astype(np.float32)
+    widths = [int(w) for w in rs.randint(1, 200, NL)]
+    Ds = [rs.randn(R, w).astype(np.float32) for w in widths]
+    AL = rs.randn(R, 33).astype(np.float32)
+    cat = np.stack([rs.randint(0, v, B) for v in vocab], 1).astype(np.int32)
+    out = rs.randn(R).astype(np.float32)
+    slopes = (1 + 0.3 * rs.randn(B)).astype(np.float32)
+    dD1, dW, dAL, dout, dsl = (_dev.to_dev(a) for a in (D1, W, AL, out, slopes))
+    dDs = [_dev.to_dev(a) for a in Ds]
+    catd = _dev.to_dev(cat, torch.int32)
+    sums = [_dev.empty(w) for w in widths]
+    dw, dbo = _dev.empty(33), _dev.empty(1)
+    grad = _dev.to_dev(np.full(o, 7.0, np.float32))
+    losses = _dev.empty(4)
+    inv = 1.0 / B
+    j = _lib.SmallGrads()
+    j.n_colsum = NL
+    for l in range(NL):
+        j.cs_A[l], j.cs_lda[l], j.cs_r0[l], j.cs_r1[l], j.cs_H[l], j.cs_out[l] = ptr(dDs[l]), widths[l], l % 3, 2 * B, widths[l], ptr(sums[l])
+    j.w_A, j.w_lda, j.w_R, j.w_H, j.w_n0, j.w_n1 = ptr(dAL), 33, R, 33, B, B
+    j.w_c0, j.w_c1, j.w_c2 = -inv, inv, 1.0
+    j.w_out, j.w_bias_out = ptr(dw), ptr(dbo)
+    j.emb_grad, j.emb = ptr(grad), e
+    j.emb_D, j.emb_W, j.emb_cat = ptr(dD1), ptr(dW), ptr(catd)
+    j.emb_ldd, j.emb_H, j.emb_ldw, j.emb_col0, j.emb_ld_cat, j.emb_B, j.emb_rows = H, H, H, col0, NC, B, 2 * B
+    j.l_losses, j.l_out, j.l_slopes = ptr(losses), ptr(dout), ptr(dsl)
+    j.l_n0, j.l_n1, j.l_ns = B, B, B
+    j.l_inv_b, j.l_gp_weight, j.l_fake_sign = inv, 10.0, 1.0
+    _lib.check(lib.agx_small_grads(_dev.stream(), j))
+    for l in range(NL):
+        np.testing.assert_allclose(sums[l].cpu().numpy(), Ds[l][l % 3:2 * B].astype(np.float64).sum(0), atol=2e-5)
+    c = np.concatenate([np.full(B, -inv), np.full(B, inv), np.ones(B)])
+    np.testing.assert_allclose(dw.cpu().numpy(), (c[:, None] * AL.astype(np.float64)).sum(0), atol=2e-5)
+    g = grad.cpu().numpy()
+    rows = np.arange(2 * B) % B
+    c0 = col0
+    touched = np.zeros(o, bool)
+    for i, (v, dd, of) in enumerate(zip(vocab, edim, offs)):
+        dcov = D1[:2 * B].astype(np.float64) @ W[c0:c0 + dd].astype(np.float64).T
+        want = np.zeros((v, dd))
+        np.add.at(want, cat[rows, i], dcov)
+        np.testing.assert_allclose(g[of:of + v * dd].reshape(v, dd), want, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(want).max()))
+        touched[of:of + v * dd] = True
+        c0 += dd
+    assert np.all(g[~touched] == 7.0)
+    ls = losses.cpu().numpy()
+    w = -out[:B].astype(np.float64).sum() * inv + out[B:2 * B].astype(np.float64).sum() * inv
+    gp = ((slopes.astype(np.float64) - 1) ** 2).sum() * inv
+    np.testing.assert_allclose(ls[:3], [w, gp, w + 10 * gp], rtol=1e-5, atol=1e-5)
+
+
 def test_empty_bracket_overhead_is_small_and_positive(gpu):
     """agx_prof_empty_bracket_us: what the two event records of a bracket add to the launch they
     enclose (bench.py subtracts it from the bracketed duration of the dominant kernel)."""
