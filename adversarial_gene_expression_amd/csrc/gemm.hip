@@ -1027,6 +1027,13 @@ __device__ __forceinline__ int frag_lane_off(int ld, int i, int h) {
 // launch).  Measured (profiles/r02_direct_kernel_staging.txt): 64x256x18161 14.9 -> 14.0 us, 1024x256x18161 136 ->
 // 119 us, 32x20000x1024 NT 30.4 -> 26.4 us, 32-row iteration 0.4956 -> 0.4887 ms.  Staging the A operand the same way
 // (bit 2) loses: 16.2 us and 0.530 ms - its re-reads hit L2, the extra LDS hop only adds latency to every pass.
+// What the input-gradient product (32 x 18154 x 256, one pass) spends beyond streaming W_1, part by part
+// (tools/micro/dx_parts.hip, profiles/r02_direct_kernel_staging.txt): B loads 3.9 us (2.4 in line order), + the A
+// fragments - the same 32 x 256 matrix for all 568 workgroups, L2 hits, but as many bytes into the CUs as B - 6.5,
+// + MFMAs 6.8, + cross-wave reduction 6.9, + tile stored 7.4 us.  Tried against the A term and dropped: two column
+// tiles per workgroup sharing the A fragments (284 workgroups: 18.0 against 9.2 us - hipcc keeps the second tile's
+// operands in scratch memory, and capped at 128 registers for two workgroups per CU it still does); the ragged last
+// tile shifted into the interior path (9.08 against 9.12 us: the edge workgroup is not the long pole).
 // AGX_DIRECT_STAGE bits: 1 = B of NT, 4 = B of NN, 2 = A (k-contiguous)
 #ifndef AGX_DIRECT_STAGE
 #define AGX_DIRECT_STAGE 5
