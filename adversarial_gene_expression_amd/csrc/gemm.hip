@@ -1031,8 +1031,9 @@ __device__ __forceinline__ int frag_lane_off(int ld, int i, int h) {
 // (tools/micro/dx_parts.hip, profiles/r02_direct_kernel_staging.txt): B loads 3.9 us (2.4 in line order), + the A
 // fragments - the same 32 x 256 matrix for all 568 workgroups, L2 hits, but as many bytes into the CUs as B - 6.5,
 // + MFMAs 6.8, + cross-wave reduction 6.9, + tile stored 7.4 us.  Tried against the A term and dropped: two column
-// tiles per workgroup sharing the A fragments (284 workgroups: 18.0 against 9.2 us - hipcc keeps the second tile's
-// operands in scratch memory, and capped at 128 registers for two workgroups per CU it still does); the ragged last
+// tiles per workgroup sharing the A fragments (284 workgroups: 18.0 against 9.2 us with the accumulators as an array,
+// which hipcc parks in scratch; 14.6 us with two named accumulators, with or without a 128-register cap for two
+// workgroups per CU - half as many waves to keep the stream in flight, two reductions in a row); the ragged last
 // tile shifted into the interior path (9.08 against 9.12 us: the edge workgroup is not the long pole).
 // AGX_DIRECT_STAGE bits: 1 = B of NT, 4 = B of NN, 2 = A (k-contiguous)
 #ifndef AGX_DIRECT_STAGE
