@@ -39,7 +39,14 @@ struct FusedOpt {
 };
 // raw_slabs != NULL: no reduce launch; the split-K partial slabs stay in g->ws as [M][splitk][N]
 // (also when splitk == 1) and *raw_slabs receives splitk - the caller's kernel finishes the product
-int gemm_run(void *stream, const agx_gemm_t *g, const FusedOpt *fo, int *raw_slabs);
+// dual: rows [0, dual->rows) of a plain Dense product (alpha, bias, activation; LDS-tiled kernel, no split-K) are ALSO
+// stored at dual->C (the generator's first generated batch straight into the stacked critic input: no copy launch).
+struct DualOut {
+  float *C;
+  int ldc, rows;
+};
+bool gemm_can_dual(int M, int N, int K, int64_t ws_floats, int layout);
+int gemm_run(void *stream, const agx_gemm_t *g, const FusedOpt *fo, int *raw_slabs, const DualOut *dual = nullptr);
 
 // Small-batch critic tail (two hidden layers of width <= 256): everything between the split-K slabs
 // of the first-layer product and the next big product in ONE launch per phase instead of 3 + 3.
@@ -121,9 +128,17 @@ struct IterDraws {
   int n;
   DrawSeg seg[AGX_MAX_RNG_SEGS];
 };
+// xc (optional): the same launch writes the covariate columns [col0, col0 + ncov) of rows [0, rows) of the stacked
+// critic input from the CRITIC's tables (row r takes the covariates of sample r % B)
+struct CriticCov {
+  const agx_embed_t *e = nullptr;
+  const float *tables = nullptr;
+  float *X = nullptr;
+  int ldx = 0, col0 = 0, rows = 0;
+};
 int iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const IterDraws &d, const agx_embed_t *e,
                const float *tables, const float *num, int n_num, const int32_t *cat, int ld_cat, int B, int rows_cov,
-               int zcols, float *gin0, int ldg0);
+               int zcols, float *gin0, int ldg0, const CriticCov *xc = nullptr);
 // Adam with the bias-corrected step size read from device memory (captured iterations)
 int opt_adam_dev_lr(void *stream, float *w, const float *g, float *m, float *v, int64_t n, const float *lr_dev,
                     float beta1, float beta2, float eps);

@@ -194,8 +194,10 @@ struct Gemm {  // GEMM call builder
   Gemm &interp(int rows, const float *alpha) { g.interp_rows = rows; g.interp_alpha = alpha; return *this; }
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
   Gemm &opt(const agx::FusedOpt *f) { fo = f; return *this; }
+  Gemm &dual(const agx::DualOut *d) { du = d; return *this; }
   const agx::FusedOpt *fo = nullptr;
-  int run(hipStream_t st) { return agx::gemm_run(st, &g, fo, nullptr); }
+  const agx::DualOut *du = nullptr;
+  int run(hipStream_t st) { return agx::gemm_run(st, &g, fo, nullptr, du); }
   int run_slabs(hipStream_t st, int *splitk) { return agx::gemm_run(st, &g, nullptr, splitk); }
 };
 
@@ -213,7 +215,7 @@ int gen_input(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, c
 }
 
 // generator Dense stack over rows [0, R) of gin0; activations kept in h->gh[]; output [R, x_dim]
-int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo) {
+int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo, const agx::DualOut *dual = nullptr) {
   const agx_mlp_desc_t &m = h->cfg.gen;
   const float *in = h->gin0;
   int ldin = h->ldg0;
@@ -224,6 +226,7 @@ int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo) {
     Gemm g(h, in, ldin, 0, h->gp + m.w_off[l], m.ldw[l], 0, o, ldo_l, R, m.dims[l + 1], m.dims[l]);
     g.bias(h->gp + m.b_off[l]).id(last ? AGX_K_GEN_FWD_OUT : AGX_K_GEN_FWD_HID);
     if (!last) g.act();
+    if (last) g.dual(dual);
     AGX_TRY(g.run(st));
     in = o;
     ldin = ldo_l;
@@ -733,6 +736,12 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const bool snap = seg < 0 && !a->split && !a->disc_losses && !a->gen_losses;
   const agx::LossCopy lcopy{h->loss_slot, h->losslog, (nbc + 1) * 4};
   uint64_t sub = 0;
+  // Step 0's stacked input without a copy launch (chained input assembly only): the generator's output product stores
+  // its first B rows ALSO into the fake rows of buffer 0, the draws launch writes the covariate columns.
+  static const bool fold0_on = getenv("AGX_NO_FOLD0") == nullptr;
+  const bool chainx0 = seg < 0 && fuse_d && rest_d && chain_input(h, a);
+  const bool fold0 = fold0_on && chainx0 && nbc > 0 && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
+                     agx::gemm_can_dual(S * B, gm0.dims[Lg0 + 1], gm0.dims[Lg0], h->skws_floats, 0);
   // draws + generator input in one launch (z straight into the [z | num | emb] rows) when the segment list fits
   static const bool draw_fuse_on = getenv("AGX_NO_DRAW_FUSE") == nullptr;
   const bool draw_fuse = draw_fuse_on && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS;
@@ -747,9 +756,15 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
         sub += r4u((uint64_t)Bg);
       }
     }
+    // (with the chained input assembly the same launch writes the covariate columns of step 0's [real; fake] rows
+    //  from the critic's tables, final since the last iteration; see fold0 below)
+    agx::CriticCov xc;
+    if (fold0) {
+      xc.e = &dm.emb; xc.tables = h->dp; xc.X = h->Xbuf[0]; xc.ldx = h->ldx; xc.col0 = G; xc.rows = 2 * B;
+    }
     if (in_seg(0))
       AGX_TRY(agx::iter_draws(st, a->seed, h->rngpos, dr, &gm0.emb, h->gp, h->snum, gm0.n_num, h->scat, gm0.emb.n_cat, B,
-                              S * B, Z, h->gin0, h->ldg0));
+                              S * B, Z, h->gin0, h->ldg0, fold0 ? &xc : nullptr));
   } else {
     // every draw of the iteration in one launch (per 16 segments), at the stream positions the eager
     // entry points use for the GLOBAL batch (z_k then alpha_k per critic step, then the generator
@@ -792,7 +807,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     // ONE generator forward for all nb_critic+1 z batches (generator weights are constant until the
     // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
     if (!draw_fuse) AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
-    AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx));
+    const agx::DualOut du{h->Xbuf[0] + (size_t)B * h->ldx, h->ldx, B};
+    AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx, fold0 ? &du : nullptr));
     // real rows were staged into buffer 0 rows [0,B) (agx_cgan_iter_stage) and stay there for all
     // critic steps (augmentation noise is a trace constant, :210); buffer 1 gets a copy
     if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, Xb[0], h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
@@ -801,7 +817,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     h->X = Xb[k & 1];
     if (in_seg(k)) {
       // covariate columns of [real; fake] from the CURRENT (just updated) embedding tables
-      if (!chainx || k == 0) AGX_TRY(place_fake(k, st, true));
+      if (!chainx || (k == 0 && !fold0)) AGX_TRY(place_fake(k, st, true));
       agx::FusedOpt dk = dfo;
       if (chainx) {   // step k+1's rows (the generator step's rows [0,B) when k+1 == nbc) into the other buffer
         const bool gnext = (k + 1 == nbc);

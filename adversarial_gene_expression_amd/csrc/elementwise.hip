@@ -427,7 +427,34 @@ __global__ void __launch_bounds__(256) iter_draws_kernel(const agx::IterDraws d,
                                                          agx_embed_t e, const float *__restrict__ tables,
                                                          const float *__restrict__ num, int n_num,
                                                          const int *__restrict__ cat, int ld_cat, int B, int rows_cov,
-                                                         int zcols, float *__restrict__ gin0, int ldg0, int ncov) {
+                                                         int zcols, float *__restrict__ gin0, int ldg0, int ncov,
+                                                         int gen_cov_row, agx_embed_t e2, const float *__restrict__ tables2,
+                                                         float *__restrict__ X, int ldx, int xcol0, int xrows, int ncov2) {
+  if ((int)blockIdx.y >= d.n + gen_cov_row) {
+    // covariate columns of the stacked critic input, from the critic's tables (as stack_rows_kernel writes them)
+    const long long total = (long long)xrows * ncov2;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+      const int r = (int)(idx / ncov2), b = r % B;
+      int c = (int)(idx % ncov2);
+      float v = 0.f;
+      if (c < n_num) {
+        v = num[(size_t)b * n_num + c];
+      } else {
+        c -= n_num;
+        for (int i = 0; i < e2.n_cat; ++i) {
+          if (c < e2.edim[i]) {
+            const int row = cat[(size_t)b * ld_cat + i];
+            if (row >= 0 && row < e2.vocab[i]) v = tables2[e2.table_off[i] + (size_t)row * e2.edim[i] + c];
+            break;
+          }
+          c -= e2.edim[i];
+        }
+      }
+      X[(size_t)r * ldx + xcol0 + (int)(idx % ncov2)] = v;
+    }
+    return;
+  }
   if ((int)blockIdx.y < d.n) {
     const agx::DrawSeg sg = d.seg[blockIdx.y];
     const unsigned long long offset = sg.sub_offset + (base_dev ? *base_dev : 0ull);
@@ -1184,7 +1211,7 @@ extern "C" int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_d
 
 int agx::iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const agx::IterDraws &d, const agx_embed_t *e,
                     const float *tables, const float *num, int n_num, const int32_t *cat, int ld_cat, int B,
-                    int rows_cov, int zcols, float *gin0, int ldg0) {
+                    int rows_cov, int zcols, float *gin0, int ldg0, const agx::CriticCov *xc) {
   AGX_CHECK_ARG(d.n > 0 && d.n <= AGX_MAX_RNG_SEGS && e && gin0 && B > 0 && rows_cov >= 0, "iter_draws: bad argument");
   long long nmax = 0;
   for (int i = 0; i < d.n; ++i) {
@@ -1197,9 +1224,22 @@ int agx::iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const
   AGX_CHECK_ARG(ldg0 >= zcols + ncov && (n_num == 0 || num) && (e->n_cat == 0 || (cat && tables && ld_cat >= e->n_cat)),
                 "iter_draws: generator input description");
   const int cov_row = (rows_cov > 0 && ncov > 0) ? 1 : 0;
-  hipLaunchKernelGGL(iter_draws_kernel, dim3(grid_for((nmax + 3) / 4, 256, 256), d.n + cov_row), dim3(256), 0,
+  agx_embed_t e2 = {};
+  int ncov2 = 0, x_row = 0;
+  if (xc && xc->rows > 0) {
+    AGX_CHECK_ARG(xc->e && xc->X && xc->e->n_cat == e->n_cat && (xc->e->n_cat == 0 || xc->tables),
+                  "iter_draws: critic covariate description");
+    e2 = *xc->e;
+    ncov2 = n_num;
+    for (int i = 0; i < e2.n_cat; ++i) ncov2 += e2.edim[i];
+    AGX_CHECK_ARG(xc->ldx >= xc->col0 + ncov2, "iter_draws: critic input too narrow");
+    x_row = ncov2 > 0 ? 1 : 0;
+  }
+  hipLaunchKernelGGL(iter_draws_kernel, dim3(grid_for((nmax + 3) / 4, 256, 256), d.n + cov_row + x_row), dim3(256), 0,
                      agx::as_stream(stream), d, (unsigned long long)seed, (const unsigned long long *)base_dev, *e, tables,
-                     num, n_num, cat, ld_cat, B, rows_cov, zcols, gin0, ldg0, ncov);
+                     num, n_num, cat, ld_cat, B, rows_cov, zcols, gin0, ldg0, ncov, cov_row, e2,
+                     x_row ? xc->tables : nullptr, x_row ? xc->X : nullptr, x_row ? xc->ldx : 0, x_row ? xc->col0 : 0,
+                     x_row ? xc->rows : 0, ncov2);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

@@ -47,6 +47,8 @@ struct KParams {
   float *rowsq;           // [M, rowsq_ld]: per 32-column slab sum of squares of the stored values
   int rowsq_ld;
   float *ws;
+  float *c2;              // dual store: rows [0, c2_rows) of a plain product also go here (ld ldc2)
+  int ldc2, c2_rows;
   int splitk, kchunk;
   int to_ws;              // 1: the main kernel stores raw partial slabs (also when splitk == 1)
   int ws_by_row;          // slab layout, see slab_off
@@ -762,6 +764,25 @@ gemm_kernel(const KParams p) {
       };
       if (m0 + BM <= p.M && n0 + BN <= p.N) store_all(std::true_type{});
       else store_all(std::false_type{});
+      if (!raw && p.c2 && m0 < p.c2_rows) {   // dual store of the leading rows, behind all the main stores
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+            const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+            float *__restrict__ cb = p.c2 + (size_t)rbase * p.ldc2 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = (r & 3) + 8 * (r >> 2);
+              float x = acc[i][j][r] * p.alpha;
+              if (p.bias) x += epre[j][0];
+              if (p.act) x = x > 0.f ? x : x * p.slope;
+              if (rbase + ro < min(p.M, p.c2_rows) && col < p.N) cb[ro * p.ldc2] = x;
+            }
+          }
+        }
+      }
     }
   }
   if (!stored) {
@@ -1532,12 +1553,17 @@ extern "C" int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K) {
 
 extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) { return agx::gemm_run(stream, g, nullptr, nullptr); }
 
+bool agx::gemm_can_dual(int M, int N, int K, int64_t ws_floats, int layout) {
+  const Plan pl = make_plan(M, N, K, -1, 0, ws_floats, layout);
+  return (pl.cfg == 0 || pl.cfg == 1 || pl.cfg == 2 || pl.cfg == 5) && pl.splitk == 1;
+}
+
 bool agx::gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats) {
   const Plan pl = make_plan(M, N, K, -1, 0, ws_floats, 2);
   return (pl.cfg == 0 || pl.cfg == 1) && pl.splitk == 1;
 }
 
-int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, int *raw_slabs) {
+int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, int *raw_slabs, const agx::DualOut *dual) {
   AGX_CHECK_ARG(g != nullptr, "agx_gemm_f32: null descriptor");
   AGX_CHECK_ARG(g->M >= 0 && g->N >= 0 && g->K >= 0, "agx_gemm_f32: negative dimension");
   if (g->M == 0 || g->N == 0) return AGX_OK;
@@ -1620,6 +1646,14 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   p.splitk = pl.splitk;
   p.kchunk = pl.kchunk;
   p.to_ws = pl.splitk > 1;
+  if (dual && dual->rows > 0) {
+    // (callers ask gemm_can_dual first)
+    AGX_CHECK_ARG(dual->C && dual->ldc >= g->N && !opt && !raw_slabs && g->interp_rows == 0 && !g->rowscale && !g->addrow &&
+                      !g->mask && !g->accumulate && !g->rowsq && !g->col_scale && pl.splitk == 1 &&
+                      (pl.cfg == 0 || pl.cfg == 1 || pl.cfg == 2 || pl.cfg == 5) && g->force_cfg < 0,
+                  "agx_gemm_f32: dual output needs a plain Dense product on the tiled kernel (cfg %d, split-K %d)", pl.cfg, pl.splitk);
+    p.c2 = dual->C; p.ldc2 = dual->ldc; p.c2_rows = dual->rows;
+  }
   if (raw_slabs) {
     // the caller's own kernel finishes the product: leave the split-K slabs ws[z][M][N] unreduced
     AGX_CHECK_ARG(!opt && !g->rowsq && g->interp_rows == 0, "agx_gemm_f32: raw slabs combine with nothing");
