@@ -73,6 +73,10 @@ struct TailArgs {
   // interp_rows > 0, read by mode 1 as the ReLU mask), [interp_rows, lda1]
   int nsplit, out_ld;
   float *A1m;
+  // mode 2 (two hidden Dense layers of the generator from its input rows, no slabs): A1 = act(in . W1 + b1),
+  // A2 = act(A1 . W2 + b2) over rows [0, m_slab); K_in <= 128
+  const float *in; int ld_in, K_in;
+  const float *W1; int ldw1;
 };
 int critic_tail(void *stream, int mode, const TailArgs &a);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused

@@ -215,11 +215,33 @@ int gen_input(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, c
 }
 
 // generator Dense stack over rows [0, R) of gin0; activations kept in h->gh[]; output [R, x_dim]
-int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo, const agx::DualOut *dual = nullptr) {
+// batch: the rows of ONE training batch (R is a multiple of it in a captured iteration): the choice between the
+// two-layer kernel and the GEMM launches must not depend on how many batches are stacked, or the captured iteration
+// and the eager steps would round differently
+int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo, const agx::DualOut *dual = nullptr, int batch = 0) {
   const agx_mlp_desc_t &m = h->cfg.gen;
   const float *in = h->gin0;
   int ldin = h->ldg0;
-  for (int l = 0; l < m.n_layers; ++l) {
+  int l0 = 0;
+  static const bool gen_tail = getenv("AGX_NO_GEN_TAIL") == nullptr;
+  if (gen_tail && m.n_layers == 3 && m.dims[0] <= 128 && m.dims[1] <= 256 && m.dims[2] <= 256 && (batch > 0 ? batch : R) <= 64) {
+    // small batches: both hidden layers in ONE launch (tail.hip mode 2; always 4 column groups, so that a row's
+    // summation order does not depend on the number of rows)
+    agx::TailArgs t;
+    memset(&t, 0, sizeof(t));
+    t.m_slab = R; t.H1 = m.dims[1]; t.H2 = m.dims[2];
+    t.in = h->gin0; t.ld_in = h->ldg0; t.K_in = m.dims[0];
+    t.W1 = h->gp + m.w_off[0]; t.ldw1 = m.ldw[0]; t.b1 = h->gp + m.b_off[0];
+    t.W2 = h->gp + m.w_off[1]; t.ldw2 = m.ldw[1]; t.b2 = h->gp + m.b_off[1];
+    t.slope = h->cfg.slope;
+    t.A1 = h->gh[1]; t.lda1 = h->ldgh[1]; t.A2 = h->gh[2]; t.lda2 = h->ldgh[2];
+    t.nsplit = 4;
+    AGX_TRY(agx::critic_tail(st, 2, t));
+    in = h->gh[2];
+    ldin = h->ldgh[2];
+    l0 = 2;
+  }
+  for (int l = l0; l < m.n_layers; ++l) {
     const bool last = (l == m.n_layers - 1);
     float *o = last ? out : h->gh[l + 1];
     const int ldo_l = last ? ldo : h->ldgh[l + 1];
@@ -808,7 +830,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
     if (!draw_fuse) AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
     const agx::DualOut du{h->Xbuf[0] + (size_t)B * h->ldx, h->ldx, B};
-    AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx, fold0 ? &du : nullptr));
+    AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx, fold0 ? &du : nullptr, B));
     // real rows were staged into buffer 0 rows [0,B) (agx_cgan_iter_stage) and stay there for all
     // critic steps (augmentation noise is a trace constant, :210); buffer 1 gets a copy
     if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, Xb[0], h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));

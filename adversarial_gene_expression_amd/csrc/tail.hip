@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
   __shared__ float4 a1[TW];   // [k] -> the four rows' values: one ds_read_b128 per k in the Dense loop
   __shared__ float part[KQ * TR * HC];   // [q][row][column]: 4096 floats whatever NS
   __shared__ float red[16];
+  __shared__ float xin[MODE == 2 ? TR * 128 : 1];   // mode 2: the workgroup's input rows
   const int t = threadIdx.x, i = t >> 8, c = t & 255, lane = t & 63, wave = t >> 6;
   const int ns = NS > 1 ? (int)blockIdx.y : 0;
   const bool lead = ns == 0;       // the workgroup that writes what the column groups share
@@ -76,7 +77,28 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
   // (one thread per (row, column); a variant with the slabs dealt over all four thread groups and
   // 16 loads in flight per thread measured twice as slow)
   float v = 0.f;
-  if (i < nsl && c < p.H1) {
+  if (MODE == 2) {
+    // first hidden layer straight from the input rows (K_in <= 128): rows in LDS, W1 read coalesced over columns,
+    // sixteen loads in flight; k in order (one chain per element: deterministic, independent of the launch shape)
+    for (int q = t; q < TR * p.K_in; q += 1024) {
+      const int r = q / p.K_in, k = q - r * p.K_in;
+      xin[r * 128 + k] = r < nsl ? p.in[(size_t)srow(r) * p.ld_in + k] : 0.f;
+    }
+    __syncthreads();
+    if (i < nsl && c < p.H1) {
+      const float *__restrict__ w = p.W1 + c;
+      const float *xr = xin + i * 128;
+      int k = 0;
+      for (; k + 16 <= p.K_in; k += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(k + u) * p.ldw1];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v = fmaf(xr[k + u], wv[u], v);
+      }
+      for (; k < p.K_in; ++k) v = fmaf(xr[k], w[(size_t)k * p.ldw1], v);
+    }
+  } else if (i < nsl && c < p.H1) {
     const size_t stride = (size_t)p.H1;   // slabs [row][z][H1]: a row's partials are contiguous
     const float *s0 = p.ws + (size_t)srow(i) * p.splitk * p.H1 + c;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
@@ -102,7 +124,15 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
     for (; z < p.splitk; ++z) q0 += s0[(size_t)z * stride];
     v = (q0 + q1) + (q2 + q3);
   }
-  if (MODE == 0) {
+  if (MODE == 2) {
+    float a = 0.f;
+    if (i < nsl && c < p.H1) {
+      const float x = v + p.b1[c];
+      a = x > 0.f ? x : x * p.slope;
+      if (lead) p.A1[(size_t)orow(i) * p.lda1 + c] = a;
+    }
+    reinterpret_cast<float *>(&a1[c])[i] = a;
+  } else if (MODE == 0) {
     raw[i][c] = v;
     __syncthreads();
     float a = 0.f;
@@ -192,7 +222,10 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
     for (int q = 4; q < KQ; q += 4) x += (pq(q) + pq(q + 1)) + (pq(q + 2) + pq(q + 3));
     const int i = fi, c = fc;
     const size_t o = (size_t)orow(i) * p.lda2 + c;
-    if (MODE == 0) {
+    if (MODE == 2) {
+      x += p.b2[c];
+      p.A2[o] = x > 0.f ? x : x * p.slope;
+    } else if (MODE == 0) {
       x += p.b2[c];
       const float a = x > 0.f ? x : x * p.slope;
       p.A2[o] = a;
@@ -225,17 +258,30 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
 
 int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
   agx::TailArgs a = a_in;
-  AGX_CHECK_ARG(a.ws && a.splitk >= 1 && a.m_slab >= 1 && a.H1 >= 1 && a.H1 <= TW && a.H2 >= 1 && a.H2 <= TW &&
+  AGX_CHECK_ARG((mode == 2 || (a.ws && a.splitk >= 1)) && a.m_slab >= 1 && a.H1 >= 1 && a.H1 <= TW && a.H2 >= 1 && a.H2 <= TW &&
                     a.W2 && a.ldw2 >= a.H2 && a.A1 && a.A2 && a.lda1 >= a.H1 && a.lda2 >= a.H2,
                 "critic_tail: bad shapes (H1=%d H2=%d m=%d)", a.H1, a.H2, a.m_slab);
-  AGX_CHECK_ARG(a.nsplit == 0 || a.nsplit == 1 || ((a.nsplit == 2 || a.nsplit == 4) && a.out_ld > 0 && (mode == 0 || a.A1m)),
+  AGX_CHECK_ARG(a.nsplit == 0 || a.nsplit == 1 || mode == 2 || ((a.nsplit == 2 || a.nsplit == 4) && a.out_ld > 0 && (mode == 0 || a.A1m)),
                 "critic_tail: column split %d needs out_ld and the mask copy", a.nsplit);
   hipStream_t st = agx::as_stream(stream);
   // rows per workgroup: every workgroup pulls all of W2 (256 KB at 64 B/clk: 1.7 us) whatever its row count, so
   // few rows are spread over more CUs (their slab traffic per CU shrinks); many rows keep 4 per workgroup
   static const int small_rpw = getenv("AGX_TAIL_RPW") ? atoi(getenv("AGX_TAIL_RPW")) : 2;
   a.rpw = (a.interp_rows == 0 && a.m_slab <= 64) ? std::max(1, std::min(TR, small_rpw)) : TR;
-  if (mode == 0) {
+  if (mode == 2) {
+    AGX_CHECK_ARG(a.in && a.W1 && a.b1 && a.b2 && a.K_in >= 1 && a.K_in <= 128 && a.ld_in >= a.K_in && a.ldw1 >= a.H1 &&
+                      (a.nsplit == 1 || a.nsplit == 2 || a.nsplit == 4),
+                  "critic_tail: two-layer forward arguments (K_in=%d)", a.K_in);
+    a.rpw = TR;
+    a.interp_rows = 0;
+    a.row0 = 0;
+    agx::ProfScope prof(st, AGX_K_GEN_FWD_HID, 2.0 * a.m_slab * ((double)a.K_in * a.H1 + (double)a.H1 * a.H2),
+                        4.0 * ((double)a.m_slab * a.K_in + (double)a.K_in * a.H1 + (double)a.H1 * a.H2 + (double)a.m_slab * (a.H1 + a.H2)));
+    const int blocks = agx::cdiv(a.m_slab, a.rpw);
+    if (a.nsplit == 4) hipLaunchKernelGGL((critic_tail_kernel<2, 4>), dim3(blocks, 4), dim3(1024), 0, st, a);
+    else if (a.nsplit == 2) hipLaunchKernelGGL((critic_tail_kernel<2, 2>), dim3(blocks, 2), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((critic_tail_kernel<2, 1>), dim3(blocks), dim3(1024), 0, st, a);
+  } else if (mode == 0) {
     AGX_CHECK_ARG(a.b1 && a.b2 && a.w3 && a.b3 && a.D2 && a.out && a.ldd2 >= a.H2 &&
                       (a.interp_rows == 0 || (a.alpha && a.m_slab == 2 * a.interp_rows)),
                   "critic_tail: forward arguments");
