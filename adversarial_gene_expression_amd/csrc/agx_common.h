@@ -36,6 +36,9 @@ struct FusedOpt {
   const float *nx_num = nullptr;
   const int32_t *nx_cat = nullptr;
   agx_embed_t nx_emb = {};
+  // augmentation of the copied rows (tf_utils.py:209-210, :247): dst = src + nx_mask[r] * nx_noise[r * nx_ldn + g]
+  const float *nx_mask = nullptr, *nx_noise = nullptr;
+  int nx_ldn = 0;
 };
 // raw_slabs != NULL: no reduce launch; the split-K partial slabs stay in g->ws as [M][splitk][N]
 // (also when splitk == 1) and *raw_slabs receives splitk - the caller's kernel finishes the product
@@ -115,7 +118,9 @@ struct LrTable {
 // (X2: optional second stacked-input buffer that receives the same real rows)
 int iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2, int ldx, int G, int B, const int32_t *cat,
                int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
-               uint64_t rng_offset, float **loss_slot, float *losses_out, const LrTable *lrs, float *lr_dev);
+               uint64_t rng_offset, float **loss_slot, float *losses_out, const LrTable *lrs, float *lr_dev,
+               const float *aug_mask = nullptr, const float *aug_noise = nullptr, int aug_ldn = 0);
+// (aug_mask: the staged real rows get + aug_mask[b] * aug_noise[b * aug_ldn + g], tf_utils.py:210)
 // All the draws of a captured iteration AND the generator's layer-1 input in ONE launch: segment i fills
 // n values from stream position *base_dev + sub_offset (element skip + j) into out, as rows of `cols` values
 // at leading dimension `ld` when cols > 0 (z straight into the [z | num | emb] rows) and flat otherwise;

@@ -686,13 +686,14 @@ struct agx_iter_graph {
   bool snap = false;   // the last step snapshots the loss log to the address staged per launch
   bool adam = false;
   bool chainx = false; // real rows are staged into both stacked-input buffers (chain_input)
+  const float *aug_mask = nullptr, *aug_noise_real = nullptr;   // augmentation of the staged real rows (trace constants)
   agx::LrTable lrs;    // Adam: step sizes for the next replay (agx_cgan_iter_set_lr)
 };
 
 namespace {
 inline uint64_t r4u(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
 
-// One-GPU RMSprop iteration without augmentation whose critic products carry the flat update: the
+// One-GPU RMSprop iteration (with or without augmentation) whose critic products carry the flat update: the
 // layer-1 product of step k also assembles step k+1's stacked input in the OTHER stacked-input buffer
 // (generated rows + covariate columns from the freshly updated tables), so only step 0 keeps its
 // stack_rows launch.  Real rows are staged into both buffers.  Must agree between the stage call and
@@ -700,7 +701,8 @@ inline uint64_t r4u(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
 bool chain_input(const agx_cgan *h, const agx_iter_args_t *a) {
   static const bool off = getenv("AGX_NO_CHAIN_INPUT") != nullptr;
   const agx_mlp_desc_t &dm = h->cfg.disc;
-  if (off || a->split || a->opt_kind != 0 || a->nb_critic < 1 || a->aug_mask_disc || a->aug_mask_gen) return false;
+  static const bool no_aug = getenv("AGX_NO_CHAIN_AUG") != nullptr;   // (augmented iterations: per-step stack_rows launches again)
+  if (off || a->split || a->opt_kind != 0 || a->nb_critic < 1 || (no_aug && (a->aug_mask_disc || a->aug_mask_gen))) return false;
   if (getenv("AGX_NO_FUSED_OPT") || getenv("AGX_NO_FUSED_REST")) return false;
   if (h->ldsx % 4 != 0 || h->ldx % 4 != 0) return false;
   int64_t emb_end = 0;
@@ -762,7 +764,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   // its first B rows ALSO into the fake rows of buffer 0, the draws launch writes the covariate columns.
   static const bool fold0_on = getenv("AGX_NO_FOLD0") == nullptr;
   const bool chainx0 = seg < 0 && fuse_d && rest_d && chain_input(h, a);
-  const bool fold0 = fold0_on && chainx0 && nbc > 0 && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
+  const bool fold0 = fold0_on && chainx0 && nbc > 0 && !a->aug_mask_disc && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
                      agx::gemm_can_dual(S * B, gm0.dims[Lg0 + 1], gm0.dims[Lg0], h->skws_floats, 0);
   // draws + generator input in one launch (z straight into the [z | num | emb] rows) when the segment list fits
   static const bool draw_fuse_on = getenv("AGX_NO_DRAW_FUSE") == nullptr;
@@ -833,7 +835,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx, fold0 ? &du : nullptr, B));
     // real rows were staged into buffer 0 rows [0,B) (agx_cgan_iter_stage) and stay there for all
     // critic steps (augmentation noise is a trace constant, :210); buffer 1 gets a copy
-    if (a->aug_mask_disc) AGX_TRY(agx_aug_add(st, Xb[0], h->ldx, a->aug_mask_disc, a->aug_noise_real, G, 0, B, G));
+    // (augmentation noise of the real rows, :210: added by the stage launch that copies them in)
   }
   for (int k = 0; k < nbc; ++k) {
     h->X = Xb[k & 1];
@@ -850,6 +852,10 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
         dk.nx_cov = Xn; dk.nx_cov_rows = gnext ? B : 2 * B; dk.nx_B = B;
         dk.nx_num = h->snum; dk.nx_nnum = dm.n_num; dk.nx_cat = h->scat; dk.nx_ldcat = dm.emb.n_cat;
         dk.nx_emb = dm.emb;
+        // augmentation of the copied rows, as place_fake() would apply it (:209 one noise row for all, :247 a row each)
+        dk.nx_mask = gnext ? a->aug_mask_gen : a->aug_mask_disc;
+        dk.nx_noise = gnext ? a->aug_noise_gen : a->aug_noise_fake;
+        dk.nx_ldn = gnext ? G : 0;
       }
       AGX_TRY(critic_core(h, st, h->scat, B, Bg, h->abuf + (size_t)k * B, a->gp_weight,
                           a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dk : nullptr));
@@ -905,6 +911,8 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   g->snap = !a->split && !a->disc_losses && !a->gen_losses;
   g->adam = a->opt_kind == 1 && a->split != 2;   // split == 2: the caller's optimizer launches take their step size from the host
   g->chainx = chain_input(h, a);
+  g->aug_mask = a->aug_mask_disc;
+  g->aug_noise_real = a->aug_noise_real;
   g->lrs.n = 0;
   const int nseg = a->split == 2 ? a->nb_critic + 1 : (a->split ? a->nb_critic + 2 : 1);
   for (int s = 0; s < nseg; ++s) {
@@ -951,7 +959,8 @@ extern "C" int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const floa
     return AGX_E_STATE;
   }
   return agx::iter_stage(st, x, ldx, h->Xbuf[0], g->chainx ? h->Xbuf[1] : nullptr, h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum, B * nnum,
-                         h->rngpos, rng_offset, h->loss_slot, nullptr, g->adam ? &g->lrs : nullptr, h->lrdev);
+                         h->rngpos, rng_offset, h->loss_slot, nullptr, g->adam ? &g->lrs : nullptr, h->lrdev,
+                         g->aug_mask, g->aug_noise_real, h->G);
 }
 
 extern "C" int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g) { return g ? g->nseg : 0; }
@@ -979,7 +988,7 @@ extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const flo
     }
     AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], g->chainx ? h->Xbuf[1] : nullptr, h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum,
                             B * nnum, h->rngpos, rng_offset, h->loss_slot, losses_out, g->adam ? &g->lrs : nullptr,
-                            h->lrdev));
+                            h->lrdev, g->aug_mask, g->aug_noise_real, h->G));
     for (int s = 0; s < g->nseg; ++s) AGX_HIP(hipGraphLaunch(g->exec[s], st));
     return AGX_OK;
   }
@@ -1023,7 +1032,7 @@ extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_a
   const bool snap = !a->disc_losses && !a->gen_losses;
   AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], chain_input(h, a) ? h->Xbuf[1] : nullptr, h->ldx, h->G, a->B, cat, h->scat, a->B * ncat, num, h->snum,
                           a->B * nnum, h->rngpos, rng_offset, h->loss_slot, snap ? losses_out : nullptr,
-                          lrs.n ? &lrs : nullptr, h->lrdev));
+                          lrs.n ? &lrs : nullptr, h->lrdev, a->aug_mask_disc, a->aug_noise_real, h->G));
   int64_t draws = 0;
   AGX_TRY(record_iteration(h, st, a, -1, &draws));
   if (draws_out) *draws_out = draws;

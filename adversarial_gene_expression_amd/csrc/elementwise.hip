@@ -895,19 +895,30 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const SmallPlan plan,
 
 // One launch in front of a replayed iteration: real rows -> rows [0,B) of the stacked critic input,
 // covariates -> staging, RNG stream position and the loss-snapshot address -> device memory.
+template <bool AUG>
 __global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict__ x, int ldxs,
                                                          float *__restrict__ X, float *__restrict__ X2, int ldx, int G, int vec,
                                                          const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
                                                          const float *__restrict__ num, float *__restrict__ snum, int n_num,
                                                          unsigned long long *rngpos, unsigned long long rng_offset,
                                                          float **loss_slot, float *losses_out,
-                                                         const agx::LrTable lrs, float *__restrict__ lr_dev) {
+                                                         const agx::LrTable lrs, float *__restrict__ lr_dev,
+                                                         const float *__restrict__ aug_mask,
+                                                         const float *__restrict__ aug_noise, int aug_ldn) {
   const int b = blockIdx.y;
   const float *s = x + (size_t)b * ldxs;
   float *d = X + (size_t)b * ldx;
   float *d2 = X2 ? X2 + (size_t)b * ldx : nullptr;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-  if (vec) {
+  if (AUG) {   // augmented real rows (same expression as aug_add_kernel on the staged row)
+    const float m = aug_mask[b];
+    const float *nz = aug_noise + (size_t)b * aug_ldn;
+    for (int g = t0; g < G; g += stride) {
+      const float v = s[g] + m * nz[g];
+      d[g] = v;
+      if (d2) d2[g] = v;
+    }
+  } else if (vec) {
     const int g4 = G >> 2;
     for (int q = t0; q < g4; q += stride) {
       const float4 v = reinterpret_cast<const float4 *>(s)[q];
@@ -1348,14 +1359,23 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
 
 int agx::iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2, int ldx, int G, int B, const int32_t *cat,
                     int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
-                    uint64_t rng_offset, float **loss_slot, float *losses_out, const agx::LrTable *lrs, float *lr_dev) {
+                    uint64_t rng_offset, float **loss_slot, float *losses_out, const agx::LrTable *lrs, float *lr_dev,
+                    const float *aug_mask, const float *aug_noise, int aug_ldn) {
   agx::LrTable none;
   none.n = 0;
   const int vec = agx::aligned16(x) && agx::aligned16(X) && (!X2 || agx::aligned16(X2)) && ldxs % 4 == 0 && ldx % 4 == 0;
   const int gx = std::max(1, std::min(8, agx::cdiv(G, 4 * 256)));
-  hipLaunchKernelGGL(iter_stage_kernel, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, X2, ldx, G, vec,
-                     cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
-                     (unsigned long long)rng_offset, loss_slot, losses_out, (lrs && lr_dev) ? *lrs : none, lr_dev);
+  AGX_CHECK_ARG(!aug_mask || aug_noise, "iter_stage: augmentation noise missing");
+  if (aug_mask)
+    hipLaunchKernelGGL(iter_stage_kernel<true>, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, X2, ldx, G, vec,
+                       cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
+                       (unsigned long long)rng_offset, loss_slot, losses_out, (lrs && lr_dev) ? *lrs : none, lr_dev,
+                       aug_mask, aug_noise, aug_ldn);
+  else
+    hipLaunchKernelGGL(iter_stage_kernel<false>, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, X2, ldx, G, vec,
+                       cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
+                       (unsigned long long)rng_offset, loss_slot, losses_out, (lrs && lr_dev) ? *lrs : none, lr_dev,
+                       nullptr, nullptr, 0);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

@@ -73,6 +73,8 @@ struct KParams {
   // workgroups, covariate columns by update workgroup 0
   int opt_copy_blocks;
   const float *nx_src;
+  const float *nx_mask, *nx_noise;   // augmentation of the copied rows: + nx_mask[r] * nx_noise[r * nx_ldn + g]
+  int nx_ldn;
   float *nx_dst, *nx_cov;
   int nx_lds, nx_ldd, nx_rows, nx_G, nx_cov_rows, nx_B, nx_nnum, nx_ldcat;
   const float *nx_num;
@@ -145,7 +147,17 @@ __device__ __forceinline__ void next_copy(const KParams &p, int blk, int nblk) {
     const int r = (int)(q / per_row), c = (int)(q % per_row);
     const float *s = p.nx_src + (size_t)r * p.nx_lds + 4 * c;
     float *d = p.nx_dst + (size_t)r * p.nx_ldd + 4 * c;
-    if (c < g4) {
+    if (p.nx_mask) {   // same expression as stack_rows_kernel (the noise rows are not 16-B aligned: scalar loads)
+      const float m = p.nx_mask[r];
+      const float *nz = p.nx_noise + (size_t)r * p.nx_ldn + 4 * c;
+      if (c < g4) {
+        float4 v = *reinterpret_cast<const float4 *>(s);
+        v.x = v.x + m * nz[0]; v.y = v.y + m * nz[1]; v.z = v.z + m * nz[2]; v.w = v.w + m * nz[3];
+        *reinterpret_cast<float4 *>(d) = v;
+      } else {
+        for (int e = 0; e < tail; ++e) d[e] = s[e] + m * nz[e];
+      }
+    } else if (c < g4) {
       *reinterpret_cast<float4 *>(d) = *reinterpret_cast<const float4 *>(s);
     } else {
       for (int e = 0; e < tail; ++e) d[e] = s[e];
@@ -1626,6 +1638,8 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
         p.nx_lds = fo->nx_lds; p.nx_ldd = fo->nx_ldd; p.nx_rows = fo->nx_rows; p.nx_G = fo->nx_G;
         p.nx_cov_rows = fo->nx_cov_rows; p.nx_B = fo->nx_B; p.nx_nnum = fo->nx_nnum; p.nx_ldcat = fo->nx_ldcat;
         p.nx_num = fo->nx_num; p.nx_cat = fo->nx_cat; p.nx_emb = fo->nx_emb;
+        AGX_CHECK_ARG(!fo->nx_mask || (fo->nx_noise && fo->nx_ldn >= 0), "agx_gemm_f32: augmentation noise of the next input missing");
+        p.nx_mask = fo->nx_mask; p.nx_noise = fo->nx_noise; p.nx_ldn = fo->nx_ldn;
         p.opt_copy_blocks = (int)std::min<int64_t>(128, std::max<int64_t>(1, agx::cdiv64((int64_t)fo->nx_rows * (fo->nx_G / 4 + 1), 4 * 256)));
       }
     }
