@@ -1246,7 +1246,10 @@ int agx::iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const
     AGX_CHECK_ARG(xc->ldx >= xc->col0 + ncov2, "iter_draws: critic input too narrow");
     x_row = ncov2 > 0 ? 1 : 0;
   }
-  hipLaunchKernelGGL(iter_draws_kernel, dim3(grid_for((nmax + 3) / 4, 256, 256), d.n + cov_row + x_row), dim3(256), 0,
+  // (blocks along x sized for the covariate rows as well: with one block the E. coli shape - 7 tables, 192 x 24 covariate
+  //  values, a dependent cat -> table lookup each - took 20 us for this launch)
+  const long long cov_work = std::max<long long>((long long)rows_cov * ncov, x_row ? (long long)xc->rows * ncov2 : 0);
+  hipLaunchKernelGGL(iter_draws_kernel, dim3(grid_for(std::max<long long>((nmax + 3) / 4, cov_work), 256, 256), d.n + cov_row + x_row), dim3(256), 0,
                      agx::as_stream(stream), d, (unsigned long long)seed, (const unsigned long long *)base_dev, *e, tables,
                      num, n_num, cat, ld_cat, B, rows_cov, zcols, gin0, ldg0, ncov, cov_row, e2,
                      x_row ? xc->tables : nullptr, x_row ? xc->X : nullptr, x_row ? xc->ldx : 0, x_row ? xc->col0 : 0,

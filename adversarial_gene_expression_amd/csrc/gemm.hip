@@ -167,6 +167,8 @@ __device__ __forceinline__ void next_copy(const KParams &p, int blk, int nblk) {
 
 // covariate columns of the next step's rows from the embedding tables this workgroup has just updated
 // (same values as stack_rows_kernel writes: [num | emb_0 | emb_1 ...] of source row r % B)
+// (eight elements per thread in branch-free sweeps - categories, then L1-bypassing table loads, all independent -
+//  instead of one element at a time measured SLOWER: E. coli 0.3316 against 0.3208 ms, GTEx 0.4859 against 0.4840 ms)
 __device__ __forceinline__ void next_cov(const KParams &p) {
   int ncov = p.nx_nnum;
   for (int i = 0; i < p.nx_emb.n_cat; ++i) ncov += p.nx_emb.edim[i];
