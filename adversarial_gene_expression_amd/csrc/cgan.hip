@@ -764,7 +764,9 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   // its first B rows ALSO into the fake rows of buffer 0, the draws launch writes the covariate columns.
   static const bool fold0_on = getenv("AGX_NO_FOLD0") == nullptr;
   const bool chainx0 = seg < 0 && fuse_d && rest_d && chain_input(h, a);
-  const bool fold0 = fold0_on && chainx0 && nbc > 0 && !a->aug_mask_disc && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
+  // (small batches only: at 512 rows the second copy of the rows costs the product more than the launch it saves,
+  //  186.4 k against 189.6 k samples/s)
+  const bool fold0 = fold0_on && chainx0 && nbc > 0 && !a->aug_mask_disc && B <= 64 && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
                      agx::gemm_can_dual(S * B, gm0.dims[Lg0 + 1], gm0.dims[Lg0], h->skws_floats, 0);
   // draws + generator input in one launch (z straight into the [z | num | emb] rows) when the segment list fits
   static const bool draw_fuse_on = getenv("AGX_NO_DRAW_FUSE") == nullptr;

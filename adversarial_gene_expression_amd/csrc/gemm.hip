@@ -491,6 +491,9 @@ __device__ int g_stamp_m = -1, g_stamp_k = -1;   // only launches of this M / K 
 #define AGX_STAMP(i)
 #endif
 
+#ifndef AGX_DUAL_STORE
+#define AGX_DUAL_STORE 1   // 0: build without the dual-store block of the plain epilogue (A/B of its cost in every instantiation)
+#endif
 #ifndef AGX_WPE_SMALL
 #define AGX_WPE_SMALL 1
 #endif
@@ -778,7 +781,7 @@ gemm_kernel(const KParams p) {
       };
       if (m0 + BM <= p.M && n0 + BN <= p.N) store_all(std::true_type{});
       else store_all(std::false_type{});
-      if (!raw && p.c2 && m0 < p.c2_rows) {   // dual store of the leading rows, behind all the main stores
+      if (AGX_DUAL_STORE && !raw && p.c2 && m0 < p.c2_rows) {   // dual store of the leading rows, behind all the main stores
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
