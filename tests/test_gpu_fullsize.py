@@ -264,3 +264,15 @@ def test_wide_zero_slope_nan_appears_where_the_oracle_has_it(gpu):
     scale = max(1.0, np.abs(want[:first]).max())
     np.testing.assert_allclose(got[:first], want[:first], rtol=0, atol=1e-4 * scale)
     assert np.isnan(disc.get_weights()[nv]).all()      # the NaN reaches every weight of W_1, as in the reference
+
+
+def test_two_captured_iterations_match_the_oracle(gpu):
+    """Two iterations with the optimizer state carried along (see diag_two_iterations.py): after ONE RMSprop step a
+    gradient of the wrong magnitude leaves no trace in the weights; the second step exposes it."""
+    from diag_two_iterations import compare
+    r = compare(2)
+    np.testing.assert_allclose(r['losses'], r['losses64'], rtol=1e-5, atol=1e-5)
+    for tag in ('gen', 'disc'):
+        q99, q999, mx = r[tag]
+        assert q999 < 2e-6, (tag, r[tag])
+        assert q999 <= r[tag + '32'][1] + 1e-7, (tag, r[tag], r[tag + '32'])      # no worse than the torch fp32 oracle

@@ -1,0 +1,50 @@
+"""Every run-time knob of libagx selects between launch sequences that must compute the same
+iteration.  The default sequence is compared with the oracle at every BASELINE size in test_gpu_fullsize.py; here each
+knob's sequence is compared with the default's on an E. coli-sized problem (fused optimizer, chained input assembly,
+tails, the folded step-0 input and the two-layer generator kernel are all active at that size), without and with
+augmentation.  One child process per knob: the library reads its environment once."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KNOBS = [
+    ('AGX_NO_TAIL', '1'), ('AGX_NO_FUSED_OPT', '1'), ('AGX_NO_FUSED_REST', '1'), ('AGX_NO_TN_FUSE', '1'),
+    ('AGX_NO_CHAIN_INPUT', '1'), ('AGX_NO_CHAIN_AUG', '1'), ('AGX_NO_DRAW_FUSE', '1'), ('AGX_NO_FOLD0', '1'),
+    ('AGX_NO_GEN_TAIL', '1'), ('AGX_TAIL_NSPLIT', '1'), ('AGX_TAIL_NSPLIT', '2'), ('AGX_OPT_BIG_TILES', '1'),
+    ('AGX_DIRECT_NW8_MIN', '1000000'), ('AGX_TAIL_RPW', '4'),
+]
+
+
+def _run(tmp_path, name, env_extra):
+    out = str(tmp_path / (name + '.npz'))
+    env = {k: v for k, v in os.environ.items() if not k.startswith('AGX_')}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'knob_runner.py'), out], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, (name, r.stderr[-2000:])
+    return np.load(out)
+
+
+@pytest.fixture(scope='module')
+def default_run(tmp_path_factory):
+    return _run(tmp_path_factory.mktemp('knobs'), 'default', {})
+
+
+@pytest.mark.parametrize('knob,value', KNOBS, ids=['%s=%s' % kv for kv in KNOBS])
+def test_knob_sequence_computes_the_default_iteration(gpu, tmp_path, default_run, knob, value):
+    got = _run(tmp_path, 'knob', {knob: value})
+    for tag in ('plain', 'aug'):
+        ref_l, ref_w = default_run[tag + '_losses'], default_run[tag + '_w']
+        assert np.all(np.isfinite(ref_l)) and np.all(np.isfinite(got[tag + '_losses']))
+        # losses of the second iteration already depend on every update of the first
+        np.testing.assert_allclose(got[tag + '_losses'], ref_l, rtol=2e-4, atol=2e-4)
+        err = np.abs(got[tag + '_w'] - ref_w)
+        # 12 RMSprop steps of 5e-4: a differently rounded gradient moves a weight by at most a few 1e-7
+        # (see test_gpu_cgan.test_weights_after_steps for the sensitivity argument)
+        assert np.quantile(err, 0.999) < 2e-6, (knob, tag, float(np.quantile(err, 0.999)), float(err.max()))
