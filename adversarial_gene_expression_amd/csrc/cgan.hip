@@ -262,9 +262,8 @@ bool tail_ok(const agx_cgan *h, int rows) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   static const bool off = getenv("AGX_NO_TAIL") != nullptr;
   // (any batch: at 512 rows the tails still beat reduce + Dense + Dense(1) launches, 176.6 k vs 172.0 k samples/s)
-  static const int max_rows = getenv("AGX_TAIL_MAX_ROWS") ? atoi(getenv("AGX_TAIL_MAX_ROWS")) : 1 << 30;
   // (mode 1 zeroes the covariate columns of a row with one 256-thread group: ncov <= 256)
-  return !off && m.n_layers == 3 && m.dims[1] <= 256 && m.dims[2] <= 256 && h->ncov <= 256 && rows <= max_rows;
+  return !off && m.n_layers == 3 && m.dims[1] <= 256 && m.dims[2] <= 256 && h->ncov <= 256;
 }
 
 agx::TailArgs tail_args(agx_cgan *h, int splitk, int m_slab) {
@@ -701,8 +700,7 @@ inline uint64_t r4u(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
 bool chain_input(const agx_cgan *h, const agx_iter_args_t *a) {
   static const bool off = getenv("AGX_NO_CHAIN_INPUT") != nullptr;
   const agx_mlp_desc_t &dm = h->cfg.disc;
-  static const bool no_aug = getenv("AGX_NO_CHAIN_AUG") != nullptr;   // (augmented iterations: per-step stack_rows launches again)
-  if (off || a->split || a->opt_kind != 0 || a->nb_critic < 1 || (no_aug && (a->aug_mask_disc || a->aug_mask_gen))) return false;
+  if (off || a->split || a->opt_kind != 0 || a->nb_critic < 1) return false;
   if (getenv("AGX_NO_FUSED_OPT") || getenv("AGX_NO_FUSED_REST")) return false;
   if (h->ldsx % 4 != 0 || h->ldx % 4 != 0) return false;
   int64_t emb_end = 0;
@@ -733,10 +731,9 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const int64_t ghole_lo = gm0.w_off[Lg0], ghole_hi = gm0.w_off[Lg0] + (int64_t)gm0.dims[Lg0] * gm0.ldw[Lg0];
   const bool adam = a->opt_kind == 1;
   const bool fuse = seg < 0 && !a->split && B < 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
-  // from 128 rows on the critic's product always fuses (+0.7 % at 512 rows); the generator's unless AGX_FUSE_GEN_BIG=0
+  // from 128 rows on both big products fuse as well (+0.7 % at 512 rows)
   const bool fuse_big = seg < 0 && !a->split && B >= 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
-  static const bool gen_big = !(getenv("AGX_FUSE_GEN_BIG") && atoi(getenv("AGX_FUSE_GEN_BIG")) == 0);
-  const bool fuse_gbig = fuse_big && gen_big;
+  const bool fuse_gbig = fuse_big;
   const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], 3 * B, h->skws_floats);
   const bool fuse_g = (fuse || fuse_gbig) && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
@@ -762,11 +759,10 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   uint64_t sub = 0;
   // Step 0's stacked input without a copy launch (chained input assembly only): the generator's output product stores
   // its first B rows ALSO into the fake rows of buffer 0, the draws launch writes the covariate columns.
-  static const bool fold0_on = getenv("AGX_NO_FOLD0") == nullptr;
   const bool chainx0 = seg < 0 && fuse_d && rest_d && chain_input(h, a);
   // (small batches only: at 512 rows the second copy of the rows costs the product more than the launch it saves,
   //  186.4 k against 189.6 k samples/s)
-  const bool fold0 = fold0_on && chainx0 && nbc > 0 && !a->aug_mask_disc && B <= 64 && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
+  const bool fold0 = chainx0 && nbc > 0 && !a->aug_mask_disc && B <= 64 && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
                      agx::gemm_can_dual(S * B, gm0.dims[Lg0 + 1], gm0.dims[Lg0], h->skws_floats, 0);
   // draws + generator input in one launch (z straight into the [z | num | emb] rows) when the segment list fits
   static const bool draw_fuse_on = getenv("AGX_NO_DRAW_FUSE") == nullptr;

@@ -576,6 +576,33 @@ gemm_kernel(const KParams p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // SYRK (the Pearson matrix, K = number of samples, up to 100000): two-level accumulation.  Every SYRK_FLUSH K-tiles
+  // (2048 samples) the MFMA accumulators are added into a second register set and cleared, so no fp32 chain is longer
+  // than 2048 products + K/2048 partial sums: at K = 100000 the error against float64 drops from 2.8e-5 (one chain; the
+  // reference's np.dot blocks its K loop too, utils.py:824) to the 1e-6 range.  K <= 2048 never flushes: same bits as
+  // the single chain (goldens unchanged).  One v_add per accumulator register per 64 K-tiles: no measurable cost.
+  constexpr int SYRK_FLUSH = 64;
+  f32x16 acc2[SYRK ? TM : 1][SYRK ? TN : 1];
+  if (SYRK) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[SYRK ? i : 0][SYRK ? j : 0][r] = 0.f;
+  }
+  auto syrk_flush = [&](int tiles_done) {
+    if (SYRK && (tiles_done & (SYRK_FLUSH - 1)) == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc2[SYRK ? i : 0][SYRK ? j : 0] += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
+  };
 
   // fused optimizer with one 32x32 tile per wave: the weights and optimizer slots this lane will
   // update are requested NOW, so their round trip hides behind the whole K loop instead of
@@ -700,6 +727,7 @@ gemm_kernel(const KParams p) {
         }
       });
       __syncthreads();
+      syrk_flush(t + 1);
     }
   }
   for (; t < nt; ++t) {
@@ -728,6 +756,13 @@ gemm_kernel(const KParams p) {
       TileB::store(nA + TileA::LDS_FLOATS, tid, rb, n0, p.N, k0, kend);
     }
     __syncthreads();
+    if (more) syrk_flush(t + 1);
+  }
+  if (SYRK) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += acc2[SYRK ? i : 0][SYRK ? j : 0];
   }
 
   AGX_STAMP(2);
@@ -1359,7 +1394,7 @@ template <bool TA, bool TB>
 int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int groups_per_wave) {
   dim3 grid(tiles, p.splitk, 1), block(256, 1, 1);
   // long K range per workgroup (the 18k-gene first-layer products at batch 32): 8 waves share it
-  static const int nw8_min = getenv("AGX_DIRECT_NW8_MIN") ? atoi(getenv("AGX_DIRECT_NW8_MIN")) : 200;
+  constexpr int nw8_min = 200;
   if (std::min(p.kchunk, p.K) >= nw8_min) {
     // (8 k-groups per wave per pass whatever the range - 9, 12 or 18 in flight: +5..9 us per iteration.  Re-measured with
     // phase stamps in round 2: alone, 9 groups save a pass on the 18k-gene products (13.0 -> 11.2 us and 8.4 -> 6.7 us,
@@ -1368,8 +1403,7 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
     // two longer passes of the first layer take 4.5 + 4.7 us against 4.2 + 5.4 us for the three shorter ones; balancing the passes over the waves - 144 groups as
     // 3 x 6 per wave instead of 64 + 64 + 16 - measured 5 us per iteration SLOWER; 16 waves: no gain)
     dim3 block8(512, 1, 1);
-    static const bool short4 = getenv("AGX_DIRECT8_NO_U4") == nullptr;
-    if (short4 && agx::cdiv(std::min(p.kchunk, p.K), 8) <= 32) {   // <= 4 groups per wave: all 8 waves get work
+    if (agx::cdiv(std::min(p.kchunk, p.K), 8) <= 32) {   // <= 4 groups per wave: all 8 waves get work
       if (vec) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, true, 4, 8>), grid, block8, 0, st, p);
       else hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, false, 4, 8>), grid, block8, 0, st, p);
     } else if (vec) hipLaunchKernelGGL((gemm_direct_kernel<TA, TB, true, 8, 8>), grid, block8, 0, st, p);
@@ -1510,8 +1544,7 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
       if (K > 512) {
         // (with the tail kernels reducing the slabs, 2 or 3 workgroups per CU still lose: the product
         // gains 4-7 us per iteration, the tails lose 10-35)
-        static const double mult = getenv("AGX_DIRECT_SK_MULT") ? atof(getenv("AGX_DIRECT_SK_MULT")) : 1.0;
-        sk = std::min(agx::cdiv(K, 128), agx::cdiv((int)(cus * mult), pl.tiles));
+        sk = std::min(agx::cdiv(K, 128), agx::cdiv(cus, pl.tiles));
         if (sk > agx::cdiv(K, 128)) sk = agx::cdiv(K, 128);
       }
     } else {
@@ -1655,8 +1688,8 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   // the 64x64 instantiation (one 32x32 block per wave, operands prefetched, clamp-free interior path) also serves the
   // shapes whose tile count would choose 128x128 (wide critic, 20007 x 1024 x 96: 123 -> 9x us per launch).  No
   // split-K either way, so every element keeps the k order of the unfused launch.
-  static const bool opt_small_tiles = getenv("AGX_OPT_BIG_TILES") == nullptr;
-  if (opt && opt_small_tiles && pl.cfg == 0 && pl.splitk == 1 && g->K <= 512 && g->force_cfg < 0)
+  // (128x128 tiles there: wide critic 17.0 k instead of 20.3 k samples/s, profiles/r02_ab_wide_fused_tiles.txt)
+  if (opt && pl.cfg == 0 && pl.splitk == 1 && g->K <= 512 && g->force_cfg < 0)
     pl = make_plan(g->M, g->N, g->K, 1, 1, g->ws ? g->ws_floats : 0, 2);
   // the fused epilogue exists for the LDS-tiled kernels without split-K; callers ask
   // gemm_can_fuse_opt first, so the product keeps the summation order of the unfused launch

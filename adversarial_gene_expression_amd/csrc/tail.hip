@@ -266,8 +266,8 @@ int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
   hipStream_t st = agx::as_stream(stream);
   // rows per workgroup: every workgroup pulls all of W2 (256 KB at 64 B/clk: 1.7 us) whatever its row count, so
   // few rows are spread over more CUs (their slab traffic per CU shrinks); many rows keep 4 per workgroup
-  static const int small_rpw = getenv("AGX_TAIL_RPW") ? atoi(getenv("AGX_TAIL_RPW")) : 2;
-  a.rpw = (a.interp_rows == 0 && a.m_slab <= 64) ? std::max(1, std::min(TR, small_rpw)) : TR;
+  // (4 rows per workgroup at small batches measured slower; the knob is gone)
+  a.rpw = (a.interp_rows == 0 && a.m_slab <= 64) ? 2 : TR;
   if (mode == 2) {
     AGX_CHECK_ARG(a.in && a.W1 && a.b1 && a.b2 && a.K_in >= 1 && a.K_in <= 128 && a.ld_in >= a.K_in && a.ldw1 >= a.H1 &&
                       (a.nsplit == 1 || a.nsplit == 2 || a.nsplit == 4),

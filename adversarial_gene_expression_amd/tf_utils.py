@@ -444,15 +444,18 @@ class RMSprop:
                                        self.learning_rate, self.rho, self.epsilon, grad_scale), 'agx_opt_rmsprop')
         self.iterations += 1
 
-    def apply_range(self, net, lo, n, g):
-        """Update parameters [lo, lo + n) from the gradient slice g (a rank's shard of a data-parallel step)."""
+    def apply_range(self, net, lo, n, g, advance=True):
+        """Update parameters [lo, lo + n) from the gradient slice g (a rank's shard of a data-parallel step;
+        advance=False: a further piece of a step that has already been counted)."""
         lib = _lib.load()
         rms = self.slot(net)
         _lib.check(lib.agx_opt_rmsprop(_dev.stream(), net.params.data_ptr() + 4 * lo, ptr(g), rms.data_ptr() + 4 * lo, n,
                                        self.learning_rate, self.rho, self.epsilon, 1.0), 'agx_opt_rmsprop')
-        self.iterations += 1
+        self.iterations += int(bool(advance))
 
     def state_arrays(self, net):
+        """Optimizer slots in Keras variable order.  Under torch.distributed this is a COLLECTIVE (every rank
+        holds only its own shares of the slots): call it on every rank, e.g. from an all-rank save hook."""
         return {'rms': net._unflatten(_gathered_slot(net, self.slot(net)).cpu().numpy())}
 
 
@@ -485,16 +488,17 @@ class Adam:
                                     lr_t, self.beta_1, self.beta_2, self.epsilon, grad_scale), 'agx_opt_adam')
         self.iterations += 1
 
-    def apply_range(self, net, lo, n, g):
+    def apply_range(self, net, lo, n, g, advance=True):
         lib = _lib.load()
         st = self.slot(net)
-        st[2] += 1
+        st[2] += int(bool(advance))
         _lib.check(lib.agx_opt_adam(_dev.stream(), net.params.data_ptr() + 4 * lo, ptr(g), st[0].data_ptr() + 4 * lo,
                                     st[1].data_ptr() + 4 * lo, n, self.lr_t(st[2]), self.beta_1, self.beta_2, self.epsilon,
                                     1.0), 'agx_opt_adam')
-        self.iterations += 1
+        self.iterations += int(bool(advance))
 
     def state_arrays(self, net):
+        """As RMSprop.state_arrays: a COLLECTIVE under torch.distributed."""
         st = self.slot(net)
         return {'m': net._unflatten(_gathered_slot(net, st[0]).cpu().numpy()),
                 'v': net._unflatten(_gathered_slot(net, st[1]).cpu().numpy())}
@@ -665,46 +669,96 @@ def _exchange_layout(net, world, rank):
     return total, shard, rank * shard
 
 
+def _dp_chunks():
+    """Pieces of the data-parallel exchange (AGX_DP_CHUNKS; 0 = one piece: the flat one-shard-per-rank layout).
+    It fixes which rank owns which optimizer slots, so it must not change during a run."""
+    return int(os.environ.get('AGX_DP_CHUNKS', '4'))
+
+
+def _big_kernel(net):
+    """(layer, flat offset, rows, ld) of the network's largest Dense kernel (critic: W_1, generator: W_out)."""
+    l = max(range(len(net.dims) - 1), key=lambda i: net.dims[i] * net.ldw[i])
+    return l, net.w_off[l], net.dims[l], net.ldw[l]
+
+
+def _exchange_rows(net, chunks):
+    """Row boundaries [r_0 = 0, r_1, ..., r_C = rows] of the largest kernel's `chunks` row blocks (multiples of
+    64 rows: whole tiles of its weight-gradient product, 16-B aligned operand offsets)."""
+    _, _, rows, _ = _big_kernel(net)
+    if chunks <= 1:
+        return [0, rows]
+    cuts = sorted({min(rows, int(round(c * rows / chunks / 64.0)) * 64) for c in range(1, chunks)} - {0, rows})
+    return [0] + cuts + [rows]
+
+
+def _exchange_pieces(net, world, chunks=0):
+    """[(start, per)]: contiguous pieces [start, start + per * world) of the flat gradient / parameter buffers
+    that tile [0, total); rank r owns [start + r * per, start + (r + 1) * per) of each piece (reduce-scatter
+    target, optimizer slots, all-gather source).  chunks <= 1: ONE piece (the flat layout of
+    `_exchange_layout`).  Otherwise piece c ends where row block c of the largest kernel ends (rounded down to
+    a multiple of 4 * world floats; `_exchange_rows`), so that it is complete - and can travel - as soon as
+    that row block of the weight-gradient product is; the last piece also holds everything behind the kernel
+    (biases, small kernels, loss slots).  Every piece and every rank's share of it is 16-B aligned."""
+    total, shard, _ = _exchange_layout(net, world, 0)
+    if chunks <= 1:
+        return [(0, shard)]
+    q = 4 * world
+    _, off, rows, ld = _big_kernel(net)
+    bounds = [0] + [(off + r * ld) // q * q for r in _exchange_rows(net, chunks)[1:-1]] + [total]
+    bounds = sorted(set(bounds))
+    return [(a, (b - a) // world) for a, b in zip(bounds[:-1], bounds[1:])]
+
+
 def _dp_update(net, opt):
-    """Data-parallel optimizer step over xGMI: reduce-scatter the flat gradient buffer (each rank receives
-    the sum of its 1/R shard), apply the optimizer to that shard only (the 94 MB RMSprop pass of the GTEx
-    critic becomes 94/R MB per GPU; the optimizer slots of the other shards are never touched), all-gather
-    the parameters.  Same bytes on the links as one all-reduce of the gradients.  The loss scalars sit in the
-    slots behind the gradients: their sums travel back in the parameter buffer's tail (net._pbuf[n_flat:])."""
+    """Data-parallel optimizer step over xGMI, driven from Python (the rehearsal / fall-back form; under RCCL the
+    library's own overlapped exchange `agx_cgan_dp_*` does the same on two streams): per piece of the exchange
+    layout reduce-scatter the flat gradient buffer (each rank receives the sum of its 1/R share), apply the
+    optimizer to that share only (the 94 MB RMSprop pass of the GTEx critic becomes 94/R MB per GPU; the
+    optimizer slots of the other shares are never touched), all-gather the parameters.  Same bytes on the
+    links as one all-reduce of the gradients.  The loss scalars sit in the slots behind the gradients: their
+    sums travel back in the parameter buffer's tail (net._pbuf[n_flat:])."""
     world, rank = _world()
-    total, shard, lo = _exchange_layout(net, world, rank)
-    key = (world, rank)
+    pieces = _exchange_pieces(net, world, _dp_chunks())
+    key = (world, rank, len(pieces))
     bufs = net._shards.get(key)
     if bufs is None:
-        bufs = net._shards[key] = (torch.empty(shard, dtype=net._gbuf.dtype, device=net._gbuf.device),
-                                   torch.empty(shard, dtype=net._pbuf.dtype, device=net._pbuf.device))
-    g_sh, p_sh = bufs
-    _dev.reduce_scatter_sum(g_sh, net._gbuf[:total])
-    n_upd = max(0, min(lo + shard, net.n_flat) - lo)
-    if n_upd:
-        opt.apply_range(net, lo, n_upd, g_sh)
-    else:
+        m = max(per for _, per in pieces)
+        bufs = net._shards[key] = (torch.empty(m, dtype=net._gbuf.dtype, device=net._gbuf.device),
+                                   torch.empty(m, dtype=net._pbuf.dtype, device=net._pbuf.device))
+    first = True
+    for start, per in pieces:
+        g_sh, p_sh = bufs[0][:per], bufs[1][:per]
+        lo = start + rank * per
+        _dev.reduce_scatter_sum(g_sh, net._gbuf[start:start + per * world])
+        n_upd = max(0, min(lo + per, net.n_flat) - lo)
+        if n_upd:
+            opt.apply_range(net, lo, n_upd, g_sh, advance=first)
+            first = False
+        if lo + per > net.n_flat:           # loss slots (+ padding): the reduced values themselves are what travels
+            a = max(lo, net.n_flat)
+            net._pbuf[a:lo + per].copy_(g_sh[a - lo:])
+        p_sh.copy_(net._pbuf[lo:lo + per])
+        _dev.all_gather(net._pbuf[start:start + per * world], p_sh)
+    if first:                               # this rank owns no parameter at all: the step still counts
         opt.iterations += 1
         if type(opt) is Adam:
             opt.slot(net)[2] += 1
-    if lo + shard > net.n_flat:           # loss slots (+ padding): the reduced values themselves are what travels
-        a = max(lo, net.n_flat)
-        net._pbuf[a:lo + shard].copy_(g_sh[a - lo:])
-    p_sh.copy_(net._pbuf[lo:lo + shard])
-    _dev.all_gather(net._pbuf[:total], p_sh)
 
 
 def _gathered_slot(net, slot):
-    """Optimizer slot with every rank's shard filled in (each rank only ever updates its own shard)."""
+    """Optimizer slot with every rank's share filled in (each rank only ever updates its own shares).
+    A COLLECTIVE under torch.distributed: every rank must call it (hence `state_arrays` too)."""
     world, rank = _world()
     if world == 1:
         return slot
-    total, shard, lo = _exchange_layout(net, world, rank)
+    total = _exchange_layout(net, world, rank)[0]
     full = torch.zeros(total, dtype=slot.dtype, device=slot.device)
-    mine = torch.zeros(shard, dtype=slot.dtype, device=slot.device)
-    n = max(0, min(lo + shard, net.n_flat) - lo)
-    mine[:n] = slot[lo:lo + n]
-    _dev.all_gather(full, mine)
+    for start, per in _exchange_pieces(net, world, _dp_chunks()):
+        lo = start + rank * per
+        mine = torch.zeros(per, dtype=slot.dtype, device=slot.device)
+        n = max(0, min(lo + per, net.n_flat) - lo)
+        mine[:n] = slot[lo:lo + n]
+        _dev.all_gather(full[start:start + per * world], mine)
     return full[:net.n_flat]
 
 

@@ -8,7 +8,12 @@ Device tensors (torch, cuda) in -> ``DeviceArray`` out (no host round trip).
 Precision: like NumPy, the arithmetic follows the input dtype.  float32 inputs take
 the fp32 path (exact-fp32 MFMA, the throughput path); float64 inputs (the reference's
 E. coli notebooks pass float64) take a float64 path end to end (fp64 matrix cores,
-``agx_*_f64``), so they agree with the reference to float64 rounding.
+``agx_*_f64``): matrices agree with the reference to ~1e-12, the scalar Gamma to ~1e-10
+(its five sums are raw fp64 moments of distances with mean ~1: three to four digits
+of cancellation out of sixteen).  The float64 path is sized for the E. coli shapes
+(N <= ~1000, G <= ~4300: a few ms; it computes the full G x G product from global
+memory); a float64 caller at GTEx size gets correct results some 20x slower than the
+fp32 path - cast to float32 for throughput.
 """
 import numpy as np
 import torch
@@ -86,11 +91,16 @@ def _corr_dev64(x, y=None):
 
 
 def _r_from_sums64(s, n):
+    """Pearson r from the five raw moment sums.  A (numerically) constant vector has no defined correlation: the
+    reference divides 0 by 0 there and returns NaN (utils.py:816-824); raw moments would leave a rounding-level
+    covariance over a zero variance (+-inf), so non-positive variances map to NaN explicitly."""
     with np.errstate(all='ignore'):
         ma, mb = s[0] / n, s[1] / n
         va, vb = s[2] / n - ma * ma, s[3] / n - mb * mb
         cov = s[4] / n - ma * mb
-        return np.float64(cov / (np.sqrt(max(va, 0.0)) * np.sqrt(max(vb, 0.0))))
+        if not (va > 0.0 and vb > 0.0):
+            return np.float64(np.nan)
+        return np.float64(cov / (np.sqrt(va) * np.sqrt(vb)))
 
 
 def _gamma_coef64(x, y):
@@ -99,7 +109,8 @@ def _gamma_coef64(x, y):
     cx, cy = _corr_dev64(x), _corr_dev64(y)
     g = cx.shape[0]
     sums = _dev.zeros(8, dtype=torch.float64)
-    _lib.check(lib.agx_gamma_sums_f64(_dev.stream(), ptr(cx), g, ptr(cy), g, g, ptr(sums), ptr(_sums_ws())),
+    ws = _sums_ws()
+    _lib.check(lib.agx_gamma_sums_f64(_dev.stream(), ptr(cx), g, ptr(cy), g, g, ptr(sums), ptr(ws)),
                'agx_gamma_sums_f64')
     s = sums.cpu().numpy()
     if s[5] == 0:
@@ -177,18 +188,29 @@ def _pearson_1d_dev(a, b, one_minus=False):
     lib = _lib.load()
     n = a.numel()
     sums = _dev.zeros(8, dtype=torch.float64)
+    ws = _sums_ws()      # bound to a local: the scratch must outlive the launches that use it on any stream
     if a.dtype == torch.float64:
-        _lib.check(lib.agx_pearson_sums_f64(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums), ptr(_sums_ws())),
+        _lib.check(lib.agx_pearson_sums_f64(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums), ptr(ws)),
                    'agx_pearson_sums_f64')
         return _r_from_sums64(sums.cpu().numpy(), n)
-    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums), ptr(_sums_ws())),
+    _lib.check(lib.agx_pearson_sums(_dev.stream(), ptr(a), ptr(b), n, int(one_minus), ptr(sums), ptr(ws)),
                'agx_pearson_sums')
     return _r_from_sums(sums.cpu().numpy(), n)
 
 
+_SUMS_WS = {}
+
+
 def _sums_ws():
-    """Scratch for the workgroups' partial sums of the deterministic five-sum reductions."""
-    return _dev.empty(int(_lib.load().agx_sums_ws_doubles()), dtype=torch.float64)
+    """Scratch for the workgroups' partial sums of the deterministic five-sum reductions: ONE tensor per device,
+    kept for the life of the process (a temporary would go back to the caching allocator before the kernels that
+    write it have run, which is only safe while everything stays on one stream).  Calls that overlap on
+    different streams of one device would share it: the eval helpers are single-stream."""
+    dev = _dev.device()
+    t = _SUMS_WS.get(dev.index)
+    if t is None:
+        t = _SUMS_WS[dev.index] = torch.empty(int(_lib.load().agx_sums_ws_doubles()), dtype=torch.float64, device=dev)
+    return t
 
 
 def _r_from_sums(s, n):
@@ -196,7 +218,9 @@ def _r_from_sums(s, n):
         ma, mb = s[0] / n, s[1] / n
         va, vb = s[2] / n - ma * ma, s[3] / n - mb * mb
         cov = s[4] / n - ma * mb
-        return np.float32(cov / (np.sqrt(max(va, 0.0)) * np.sqrt(max(vb, 0.0))))
+        if not (va > 0.0 and vb > 0.0):      # constant vector: the reference's 0 / 0 (utils.py:816-824)
+            return np.float32(np.nan)
+        return np.float32(cov / (np.sqrt(va) * np.sqrt(vb)))
 
 
 def _triu_pack_dev(c, ldc, g):

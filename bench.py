@@ -361,10 +361,19 @@ def cpu_baseline(workload, B, budget_s=15.0, nb_critic=5):
     cc = torch.tensor(np.stack([rs.randint(0, v, B) for v in V], 1))
     nc = torch.zeros(B, n_num)
 
+    kd, kg = {}, {}
+    if P_AUG.get(workload, 0):       # ecoli_gan.py:90: p_aug = 0.25, constants per trace (tf_utils.py:202-210, :240-247)
+        pa = P_AUG[workload]
+        kd = dict(aug_mask=torch.tensor(rs.binomial(1, pa, B), dtype=torch.float32),
+                  aug_noise_fake=torch.tensor(rs.normal(0, 0.5, G), dtype=torch.float32),
+                  aug_noise_real=torch.tensor(rs.normal(0, 0.5, (B, G)), dtype=torch.float32))
+        kg = dict(aug_mask=torch.tensor(rs.binomial(1, pa, B), dtype=torch.float32),
+                  aug_noise=torch.tensor(rs.normal(0, 0.5, (B, G)), dtype=torch.float32))
+
     def iteration():
         for _ in range(nb_critic):
-            O.train_disc(x, torch.randn(B, Z), cc, nc, gp, dp, do, torch.rand(B, 1))
-        O.train_gen(torch.randn(B, Z), cc, nc, gp, dp, go)
+            O.train_disc(x, torch.randn(B, Z), cc, nc, gp, dp, do, torch.rand(B, 1), **kd)
+        O.train_gen(torch.randn(B, Z), cc, nc, gp, dp, go, **kg)
 
     iteration()  # warm-up
     n, t0 = 0, time.perf_counter()
@@ -378,6 +387,51 @@ def cpu_baseline(workload, B, budget_s=15.0, nb_critic=5):
                 sample='%d iterations (5 critic + 1 generator steps, batch %d, %s shape) of the torch-CPU fp32 '
                        'restatement of tf_utils.py:186-258 in %.1f s; TensorFlow itself is unavailable offline'
                        % (n, B, workload, el))
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU) of this
+    very command with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, BEFORE anything in this process has
+    touched the GPU (children are spawned, nothing is exec'ed over an initialised process).  Rank 0's stdout
+    (the one JSON line) passes through; the exit code is the first non-zero child's.  If one rank dies the
+    others are ended by their exact PIDs (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, '-u', os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 128 - c
+                print('bench.py: rank %d exited with %d; ending the other ranks' % (procs.index(p), c), file=sys.stderr)
+                deadline = time.time() + 20
+                while time.time() < deadline and any(q.poll() is None for q in live):
+                    time.sleep(0.2)
+                for q in live:
+                    if q.poll() is None:
+                        q.terminate()
+                deadline = time.time() + 10
+                while time.time() < deadline and any(q.poll() is None for q in live):
+                    time.sleep(0.2)
+                for q in live:
+                    if q.poll() is None:
+                        q.kill()
+    return rc
 
 
 def main():
@@ -395,10 +449,19 @@ def main():
                     help='skip the E. coli / wide batch-32 throughput entries')
     a = ap.parse_args()
 
-    import torch
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (nothing has touched the GPU yet)
+        sys.exit(self_launch(a.gpus))
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('AGX_BENCH_LAUNCH_ONLY'):
+        # launcher rehearsal without a GPU (tests/test_host_logic.py): each rank reports and leaves
+        if rank == 0:
+            print(json.dumps({'launch_only': True, 'world': world, 'master': os.environ.get('MASTER_ADDR')}))
+        sys.exit(int(os.environ.get('AGX_BENCH_LAUNCH_RC_%d' % rank, '0')))
+    import torch
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get('AGX_DIST_BACKEND', 'nccl')   # 'gloo' lets several ranks share one GPU (rehearsal only)
@@ -408,9 +471,8 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)
-    if a.gpus != world and rank == 0 and world == 1 and a.gpus > 1:
-        print('bench.py: --gpus %d needs torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus), file=sys.stderr)
-        sys.exit(2)
+    if a.gpus != world and rank == 0:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d: measuring %d rank(s)' % (a.gpus, world, world), file=sys.stderr)
 
     res = run_gpu(a.workload, a.batch, a.steps, a.warmup, world, rank)
     G, V, n_num, H, Z = WORKLOADS[a.workload]
@@ -456,6 +518,15 @@ def main():
                                  whole_iter_tflops=algorithmic_flops_per_iter(Gx, Vx, nx, Hx, Zx, 32) / (r['ms_per_step'] * 1e-3) / 1e12)
             except Exception as e:
                 extra[wl] = {'error': repr(e)[:200]}
+        try:   # configs[4] in the MFMA-bound regime as well
+            r = run_gpu('wide', 512, max(5, a.steps // 20), 2, 1, 0, roofline=False)
+            Gx, Vx, nx, Hx, Zx = WORKLOADS['wide']
+            fl = algorithmic_flops_per_iter(Gx, Vx, nx, Hx, Zx, 512)
+            extra['wide_b512'] = dict(value=r['value'], unit='samples/s', ms_per_step=r['ms_per_step'], G=Gx, h=Hx, batch=512,
+                                      final_losses=r['final_losses'], whole_iter_tflops=fl / (r['ms_per_step'] * 1e-3) / 1e12,
+                                      whole_iter_mfma_frac=fl / (r['ms_per_step'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF)
+        except Exception as e:
+            extra['wide_b512'] = {'error': repr(e)[:200]}
         line['extra'] = extra
     if a.corr_n > 0:
         try:
@@ -465,6 +536,10 @@ def main():
         line['corr'] = corr
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(a.workload, a.batch)
+        if 'extra' in line:    # BASELINE.json configs[0]: the E. coli cGAN on the CPU path (as shipped, and all genes)
+            for wl in ('ecoli_crp', 'ecoli'):
+                if isinstance(line['extra'].get(wl), dict) and 'value' in line['extra'][wl]:
+                    line['extra'][wl]['cpu_baseline'] = cpu_baseline(wl, 32, budget_s=5.0)
         line['corr_cpu_baseline'] = corr_cpu_baseline()
     if rank == 0:
         print(json.dumps(line))

@@ -74,9 +74,9 @@ class _SgdStub:
     def __init__(self):
         self.iterations = 0
 
-    def apply_range(self, net, lo, n, g):
+    def apply_range(self, net, lo, n, g, advance=True):
         net.params[lo:lo + n] -= 0.5 * g[:n]
-        self.iterations += 1
+        self.iterations += int(advance)
 
 
 def _exchange_worker(rank, world, port, out_dir):
@@ -85,14 +85,21 @@ def _exchange_worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from adversarial_gene_expression_amd import tf_utils as T
-        for n_flat in (64, 192, 4096 + 64):      # first: the loss slots fall into the LAST rank's shard only
+        # (n_flat, exchange pieces): first: the loss slots fall into the LAST rank's shard only; the chunked
+        # layouts cut the 'kernel' (rows x ld at offset 64) into row blocks of 64 rows
+        for n_flat, chunks in ((64, 0), (192, 0), (4096 + 64, 0), (64 + 300 * 8 + 64, 3), (64 + 1000 * 12 + 128, 4),
+                               (64 + 50 * 8, 4)):
+            os.environ['AGX_DP_CHUNKS'] = str(chunks)
             rs = np.random.RandomState(n_flat)
             w0 = rs.randn(n_flat).astype(np.float32)
             size = n_flat + T._LOSS_SLOTS + T._EXCH_SLACK
             pbuf, gbuf = torch.zeros(size), torch.zeros(size)
             pbuf[:n_flat] = torch.from_numpy(w0)
+            ld = 12 if n_flat == 64 + 1000 * 12 + 128 else 8
+            rows = max(1, (n_flat - 128) // ld)
             net = SimpleNamespace(n_flat=n_flat, _pbuf=pbuf, _gbuf=gbuf, params=pbuf[:n_flat],
-                                  grads=gbuf[:n_flat + T._LOSS_SLOTS], _shards={})
+                                  grads=gbuf[:n_flat + T._LOSS_SLOTS], _shards={},
+                                  dims=[rows, ld, 1], ldw=[ld, 1], w_off=[64, 64 + rows * ld])
             grs = [np.random.RandomState(1000 + r).randn(n_flat).astype(np.float32) for r in range(world)]
             gbuf[:n_flat] = torch.from_numpy(grs[rank])
             gbuf[n_flat + 2] = 1.5 + rank                 # this rank's share of the loss scalar
@@ -104,6 +111,20 @@ def _exchange_worker(rank, world, port, out_dir):
             assert opt.iterations == 1
             total, shard, lo = T._exchange_layout(net, world, rank)
             assert total % (4 * world) == 0 and total >= n_flat + T._LOSS_SLOTS and shard * world == total
+            pieces = T._exchange_pieces(net, world, chunks)
+            assert pieces[0][0] == 0 and pieces[-1][0] + pieces[-1][1] * world == total
+            assert all(a[0] + a[1] * world == b[0] for a, b in zip(pieces, pieces[1:]))
+            assert all(st % 4 == 0 and per % 4 == 0 and per > 0 for st, per in pieces)
+            assert len(pieces) == (1 if chunks <= 1 else len(T._exchange_rows(net, chunks)) - 1)
+            if chunks > 1 and rows >= 64 * chunks:
+                assert len(pieces) == chunks
+            # the slots come back assembled from every rank's shares (a collective)
+            slot = torch.zeros(n_flat)
+            for st, per in pieces:
+                a, b = st + rank * per, min(st + (rank + 1) * per, n_flat)
+                if b > a:
+                    slot[a:b] = torch.arange(a, b, dtype=torch.float32)
+            np.testing.assert_array_equal(T._gathered_slot(net, slot).numpy(), np.arange(n_flat, dtype=np.float32))
         open(os.path.join(out_dir, 'ex%d' % rank), 'w').write('ok')
     finally:
         dist.destroy_process_group()
@@ -112,7 +133,7 @@ def _exchange_worker(rank, world, port, out_dir):
 def test_reduce_scatter_sharded_update_all_gather(tmp_path):
     """tf_utils._dp_update on CPU tensors over gloo (2 and 3 ranks): reduce-scatter of the flat gradient
     buffer, optimizer on the own shard, all-gather of the parameters == full-gradient update everywhere;
-    the loss scalars behind the gradients come back summed."""
+    the loss scalars behind the gradients come back summed.  Flat (one piece) and chunked exchange layouts."""
     for world in (2, 3):
         d = tmp_path / ('w%d' % world)
         d.mkdir()

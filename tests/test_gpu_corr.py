@@ -211,8 +211,8 @@ def test_corr_100k_samples_properties(gpu):
     """BASELINE.json configs[3]: the Pearson matrix of a 100000 x 18154 matrix (fp32 accumulation over
     K = 100000 samples), through the C-ABI calls bench.py times (agx_colstats, agx_standardize,
     agx_corr_xtx).  Size-independent properties + a fp64 spot block (utils.py:816-824):
-    bitwise symmetry, |diag - 1| and |r| <= 1 within 5e-5, a 64 x 64 block of random gene pairs within
-    5e-5 of the float64 value (genes carry offsets up to +-5 and scales 0.2..3: centring happens before
+    bitwise symmetry, |diag - 1| and |r| <= 1 within 1e-5, a 64 x 64 block of random gene pairs within
+    1e-5 of the float64 value (two-level accumulation in the SYRK kernel: no fp32 chain longer than 2048 products) (genes carry offsets up to +-5 and scales 0.2..3: centring happens before
     the product exactly as in the reference)."""
     import torch
     from adversarial_gene_expression_amd import _dev, _lib
@@ -252,6 +252,6 @@ def test_corr_100k_samples_properties(gpu):
     print('corr 100000 x 18154: max|diag-1| %.3g, 64x64 spot max|err| %.3g, max|r| %.7f'
           % (diag_err, spot_err, float(cg.abs().max())))
     assert float(ref.abs().min()) < 0.05 and float((ref - torch.eye(64, device='cuda')).abs().max()) > 0.3
-    assert diag_err < 5e-5
-    assert float(cg.abs().max()) <= 1 + 5e-5
-    assert spot_err < 5e-5
+    assert diag_err < 1e-5
+    assert float(cg.abs().max()) <= 1 + 1e-5
+    assert spot_err < 1e-5

@@ -37,3 +37,25 @@ def test_shard_partitions_the_batch(n, world):
         assert b == c
     sizes = [b - a for a, b in cuts]
     assert max(sizes) - min(sizes) <= 1
+
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (RANK / WORLD_SIZE / MASTER_* set),
+    relays rank 0's JSON line and returns a failing rank's exit code (rehearsal mode: no GPU is touched)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['AGX_BENCH_LAUNCH_ONLY'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'launch_only': True, 'world': 4, 'master': '127.0.0.1'}
+    env['AGX_BENCH_LAUNCH_RC_2'] = '7'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 7, (r.returncode, r.stderr)
