@@ -46,6 +46,8 @@ class GemmDesc(C.Structure):
         ('interp_alpha', C.c_void_p),
         ('col_scale', C.c_void_p),
         ('col_shift', C.c_void_p),
+        ('sk_flags', C.c_void_p),
+        ('sk_flag_words', C.c_int32),
     ]
 
 
@@ -158,6 +160,7 @@ SIGNATURES = {
     'agx_sizeof': (_i64, [_i32]),
     'agx_gemm_f32': (C.c_int, [_vp, C.POINTER(GemmDesc)]),
     'agx_gemm_ws_floats': (_i64, [_i32, _i32, _i32]),
+    'agx_gemm_sk_flag_words': (_i64, []),
     'agx_bn_fold': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _i32]),
     'agx_affine_act': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _f32]),
     'agx_embed_concat_fwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32,

@@ -63,6 +63,9 @@ struct agx_cgan {
   int ldsx = 0;
   float *skws = nullptr;                    // split-K scratch
   int64_t skws_floats = 0;
+  uint32_t *skflags = nullptr;              // stream-K hand-off words (zeroed at bind, self-cleaning)
+  int skflag_words = 0;
+  bool use_sk = false;                      // set while the segments of a data-parallel iteration are recorded
   int64_t ws_floats_total = 0;
 };
 
@@ -167,6 +170,8 @@ void carve(agx_cgan *h, float *base) {
   }
   h->skws_floats = r64(need);
   h->skws = cv.take(h->skws_floats);
+  h->skflag_words = (int)r64(agx_gemm_sk_flag_words());
+  h->skflags = reinterpret_cast<uint32_t *>(cv.take(h->skflag_words));
   h->ws_floats_total = cv.off;
 }
 
@@ -185,6 +190,15 @@ struct Gemm {  // GEMM call builder
     g.ws_floats = h->skws_floats;
     g.force_cfg = -1;
     g.force_splitk = 0;
+    hh = h;
+  }
+  agx_cgan *hh;
+  // allow the stream-K form (plain TN weight-gradient products of the data-parallel segments only: the one-GPU
+  // iteration fuses RMSprop into the static 64x64 tiling, which measured faster than stream-K + fused update -
+  // 169 against 191-200 us per 512-row dW_1 - and the eager step functions keep that tiling's summation order)
+  Gemm &sk(bool on) {
+    if (on) { g.sk_flags = hh->skflags; g.sk_flag_words = hh->skflag_words; }
+    return *this;
   }
   Gemm &bias(const float *b) { g.bias = b; return *this; }
   Gemm &act() { g.act = 1; return *this; }
@@ -437,7 +451,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     }
     Gemm g(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l], m.dims[l],
            m.dims[l + 1], R);
-    g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID);
+    g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID).sk(l == 0 && !fo && h->use_sk);
     // layer 1 in a captured iteration: rows [0,G) of W_1 (all rows with dw1_last) are updated in the
     // epilogue.  Safe: every reader of those rows (forward, input gradient, second-order product)
     // precedes this launch in stream order
@@ -615,6 +629,8 @@ extern "C" int agx_cgan_bind(agx_cgan_t *h, float *gen_params, float *gen_grads,
   }
   h->gp = gen_params; h->gg = gen_grads; h->dp = disc_params; h->dg = disc_grads;
   carve(h, static_cast<float *>(workspace));
+  // stream-K hand-off words start at zero; every launch leaves them at zero again (set-up call: not captured)
+  AGX_HIP(hipMemset(h->skflags, 0, (size_t)h->skflag_words * sizeof(uint32_t)));
   h->bound = true;
   return AGX_OK;
 }
@@ -814,7 +830,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   // alternate between the two stacked-input buffers
   const bool chainx = seg < 0 && fuse_d && rest_d && chain_input(h, a);
   float *Xb[2] = {h->Xbuf[0], chainx ? h->Xbuf[1] : h->Xbuf[0]};
-  struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; } } restore{h};
+  struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; h->use_sk = false; } } restore{h};
+  h->use_sk = a->split == 2;
   // fake rows of step k (k == nbc: the generator step's rows [0,B)) into buffer k&1; with_cov: also
   // the covariate columns of the step's rows from the CURRENT embedding tables (same launch)
   auto place_fake = [&](int k, hipStream_t s, bool with_cov = false) -> int {

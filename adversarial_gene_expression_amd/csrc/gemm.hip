@@ -83,6 +83,11 @@ struct KParams {
   // SYRK only
   long long tile_begin;
   int tiles_1d;
+  // stream-K (SK instantiations): sk_part = one BM x BN partial tile per workgroup, sk_flags[w] = "workgroup w's
+  // partial is published" (consumed and reset by the tile's finisher), sk_flags[sk_wgs] = spin-timeout word
+  float *sk_part;
+  unsigned *sk_flags;
+  int sk_wgs, sk_nxcd;
 };
 
 // float offset of row `row` of split-K slab z: [z][M][N] for the library's own reduce kernels,
@@ -512,8 +517,21 @@ constexpr int gemm_min_waves(int bm, int bn, int wm, int wn, bool opt, bool opti
 
 // OPTI: the fused-optimizer epilogue and its prefetch take a clamp-free path on interior tiles (its own
 // instantiation: compiled into the K = 1536 launches the same source measured 1-2 % SLOWER per iteration)
+//
+// SK (stream-K, TN weight-gradient products whose 128x128 tile count quantises badly over the CUs - the 512-row
+// dW_1: 284 tiles x 48 K-tiles on 256 CUs): the launch has exactly sk_wgs = 2 x CUs workgroups (all co-resident);
+// the (tile, K-tile) iteration space is dealt EVENLY and contiguously over them - independently per XCD: XCD x owns
+// tiles [x T/8, (x+1) T/8) and its workgroups blockIdx % 8 == x, so every hand-off stays inside one XCD's L2 and a
+// tile's A panel is fetched by one XCD only.  A workgroup whose share ends inside a tile publishes its accumulators as
+// a partial tile (plain stores -> every wave drains -> barrier -> one lane: agent-scope release, relaxed flag store);
+// the workgroup that reaches the tile's END is its finisher: it polls the flags of the (lower-numbered) workgroups
+// that hold the tile's earlier K ranges (bounded spin, relaxed), acquires once, adds their partials in ascending K
+// order and then its own accumulators, and runs the epilogue (plain store or the fused RMSprop update).  The
+// partition depends only on (shape, sk_wgs): results are bit-reproducible run to run.  A waiter only ever waits for
+// LOWER-numbered workgroups of its own XCD, which the dispatcher has started before it: no deadlock even if the
+// grid were not fully resident; the spin is bounded anyway (timeout word sk_flags[sk_wgs], checked by the tests).
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, int DBG = 0,
-          bool OPT = false, bool OPTI = false>
+          bool OPT = false, bool OPTI = false, bool SK = false>
 __global__ void __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(gemm_min_waves(BM, BN, WM, WN, OPT, OPTI))))
 gemm_kernel(const KParams p) {
   constexpr int NT = WM * WN * 64;
@@ -550,7 +568,42 @@ gemm_kernel(const KParams p) {
   // tiles of the product (an OPT launch without split-K may carry extra update workgroups behind them)
   const int gx = (OPT && p.rest_n > 0) ? p.opt_tiles : (int)gridDim.x;
 
+  // stream-K: this workgroup's contiguous share [sk_it, sk_end) of its XCD's (tile, K-tile) iteration space,
+  // walked from its END: the first thing a workgroup computes is the HEAD of its last tile (published at once as a
+  // partial), the last thing is the TAIL of its first tile, whose earlier K ranges lower-numbered workgroups
+  // published when they started - nobody waits for work that has not been done yet
+  int sk_it = 0, sk_end = 1, sk_tile_lo = 0, sk_kt = 1, sk_local = 0, sk_wx = 1, sk_ix = 0;
+  if (SK) {
+    const int nx = p.sk_nxcd;
+    const int T = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int xcd = (int)blockIdx.x % nx;
+    sk_local = (int)blockIdx.x / nx;
+    sk_wx = gx / nx;
+    sk_tile_lo = xcd * T / nx;
+    sk_kt = (p.K + BK - 1) / BK;
+    sk_ix = ((xcd + 1) * T / nx - sk_tile_lo) * sk_kt;   // (< 2^31 / sk_wx: checked on the host)
+    sk_it = sk_local * sk_ix / sk_wx;
+    sk_end = (sk_local + 1) * sk_ix / sk_wx;
+  }
+  do {   // (not stream-K: exactly one pass)
   int tm, tn, z;
+  int kbeg, kend;
+  bool sk_first = true, sk_last = true;
+  int sk_tile_it0 = 0;
+  if (SK) {
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tl = (sk_end - 1) / sk_kt;              // the LAST tile of what is left of the share
+    sk_tile_it0 = tl * sk_kt;
+    const int kt0 = max(sk_it, sk_tile_it0) - sk_tile_it0, kt1 = sk_end - sk_tile_it0;
+    sk_first = kt0 == 0;
+    sk_last = kt1 == sk_kt;
+    sk_end = sk_tile_it0 + kt0;
+    tm = (sk_tile_lo + tl) / tiles_n;
+    tn = (sk_tile_lo + tl) % tiles_n;
+    z = 0;
+    kbeg = kt0 * BK;
+    kend = min(p.K, kt1 * BK);
+  } else {
   if (SYRK) {
     tri_decode(p.tile_begin + agx::xcd_logical_id(blockIdx.x, gridDim.x), p.tiles_1d, tm, tn);
     z = 0;
@@ -564,9 +617,10 @@ gemm_kernel(const KParams p) {
     tm = t / tiles_n;
     tn = t % tiles_n;
   }
+  kbeg = z * p.kchunk;
+  kend = min(p.K, kbeg + p.kchunk);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = z * p.kchunk;
-  const int kend = min(p.K, kbeg + p.kchunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
   f32x16 acc[TM][TN];
@@ -766,6 +820,69 @@ gemm_kernel(const KParams p) {
   }
 
   AGX_STAMP(2);
+  if (SK && !sk_last) {
+    // this share ends inside the tile: publish the accumulators as this workgroup's partial tile
+    float4 *part = reinterpret_cast<float4 *>(p.sk_part) + (size_t)blockIdx.x * (BM * BN / 4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          part[((i * TN + j) * 4 + q) * NT + tid] =
+              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    continue;   // (only the first share a workgroup computes can stop short of its tile's end)
+  }
+  if (SK && !sk_first) {
+    // finisher of a tile whose earlier K ranges other workgroups hold: local ids [c_lo, sk_local) of this XCD
+    int c_lo = sk_local - 1;
+    while (c_lo > 0 && c_lo * sk_ix / sk_wx > sk_tile_it0) --c_lo;
+    if (tid == 0) {
+      for (int c = c_lo; c < sk_local; ++c) {
+        unsigned *f = p.sk_flags + ((size_t)c * p.sk_nxcd + blockIdx.x % p.sk_nxcd);
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 18)) {   // bounded: give up, leave a mark the host can read, never hang
+            __hip_atomic_store(p.sk_flags + p.sk_wgs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: ready for the next launch
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // own accumulators, then the partials in ascending K order (a fixed order: reproducible); per contributor all
+    // 16-B loads of the partial are issued together
+    for (int c = c_lo; c < sk_local; ++c) {
+      const float4 *src = reinterpret_cast<const float4 *>(p.sk_part) +
+                          ((size_t)c * p.sk_nxcd + blockIdx.x % p.sk_nxcd) * (BM * BN / 4) + tid;
+      float4 v[TM * TN * 4];
+#pragma unroll
+      for (int e = 0; e < TM * TN * 4; ++e) v[e] = src[(size_t)e * NT];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 u = v[(i * TN + j) * 4 + q];
+            acc[i][j][4 * q] += u.x;
+            acc[i][j][4 * q + 1] += u.y;
+            acc[i][j][4 * q + 2] += u.z;
+            acc[i][j][4 * q + 3] += u.w;
+          }
+    }
+  }
   // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   // per-column epilogue operands of ALL sub-tiles, requested before the first store (see epilogue_column)
   float epre[TN][3];
@@ -904,6 +1021,27 @@ gemm_kernel(const KParams p) {
               else p.C[off] = x;
             }
           }
+        } else if (OPT && m0 + BM <= min(p.M, p.opt_rows) && n0 + BN <= p.N) {
+          // interior tile of a multi-block wave tile: the 16 weights and 16 slots of this 32x32 block are requested
+          // together (one round trip per block; the general form below takes four groups of four)
+          const float omr = 1.f - p.opt_rho;
+          float *__restrict__ wb = p.opt_w + (size_t)rbase * p.ldc + col;
+          float *__restrict__ sb = p.opt_s1 + (size_t)rbase * p.ldc + col;
+          float ow[16], os[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = ((r & 3) + 8 * (r >> 2)) * p.ldc;
+            ow[r] = wb[o];
+            os[r] = sb[o];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = ((r & 3) + 8 * (r >> 2)) * p.ldc;
+            const float g = v[r] * p.alpha;
+            const float rr = p.opt_rho * os[r] + omr * (g * g);
+            sb[o] = rr;
+            wb[o] = ow[r] - p.opt_lr * g / (sqrtf(rr) + p.opt_eps);
+          }
         } else if (OPT) {
           epilogue_column<16, true>(p, rows, col, v);
         } else {
@@ -933,6 +1071,7 @@ gemm_kernel(const KParams p) {
     o[7] = tm * 100000 + tn * 100 + z;
   }
 #endif
+  } while (SK && sk_it < sk_end);   // stream-K shares (one pass otherwise)
 }
 
 // Split-K reduction + epilogue.  blockDim 256 = (256/PH lanes over 4-element chunks) x (PH split
@@ -1428,12 +1567,12 @@ int launch_direct(hipStream_t st, const KParams &p, int tiles, bool vec, int gro
 }
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false,
-          bool OPTI = false>
+          bool OPTI = false, bool SK = false>
 int launch(hipStream_t st, const KParams &p, int tiles) {
   using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
-  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT, OPTI>;  // LDS limit raised in agx_init
+  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT, OPTI, SK>;  // LDS limit raised in agx_init
   dim3 grid(tiles + ((OPT && p.rest_n > 0) ? p.opt_rest_blocks + p.opt_copy_blocks : 0), p.splitk, 1), block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);
   AGX_LAUNCH_CHECK();
@@ -1441,13 +1580,13 @@ int launch(hipStream_t st, const KParams &p, int tiles) {
 }
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC, bool SYRK, int BK = 32, bool OPT = false,
-          bool OPTI = false>
+          bool OPTI = false, bool SK = false>
 int prepare_one() {
   using TileA = Tile<BM, !TA, WM * WN * 64, VEC, BK>;
   using TileB = Tile<BN, TB, WM * WN * 64, VEC, BK>;
   constexpr size_t lds = 2 * (size_t)(TileA::LDS_FLOATS + TileB::LDS_FLOATS) * sizeof(float);
   AGX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void *>(gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT, OPTI>),
+      reinterpret_cast<const void *>(gemm_kernel<BM, BN, WM, WN, TA, TB, VEC, SYRK, BK, 0, OPT, OPTI, SK>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return AGX_OK;
 }
@@ -1479,13 +1618,49 @@ int launch_layout(hipStream_t st, const KParams &p, int tiles, int ta, int tb, b
 struct Plan {
   int cfg, bm, bn, tiles, splitk, kchunk;
   int wtm, wtn;  // wave-kernel tile (cfg >= 8)
+  int sk_wgs;    // > 0: stream-K over this many workgroups (128x128 tiles, TN)
 };
+
+// Stream-K applies (see gemm_kernel): aligned TN product, heuristic tile choice, no split-K, enough 128x128 tiles to
+// give every XCD work but a tile count that leaves the best static tiling below 92 % of its rounds, and shares of
+// >= 8 K-tiles that are no shorter than a quarter of a tile's K range (<= 5 partials per tile).
+int streamk_wgs(int M, int N, int K, int layout, int force_cfg, int force_splitk) {
+  static const bool off = getenv("AGX_NO_STREAMK") != nullptr;
+  if (off || layout != 2 || force_cfg >= 0 || force_splitk > 0) return 0;
+  const int cus = agx::num_cus();
+  if (cus % 8 != 0) return 0;
+  const long long t128 = (long long)agx::cdiv(M, 128) * agx::cdiv(N, 128);
+  const long long t64 = (long long)agx::cdiv(M, 64) * agx::cdiv(N, 64);
+  const int kt = agx::cdiv(K, BK);
+  const int wgs = 2 * cus;
+  if (t128 < cus / 2 || t128 > 16 * cus || kt < 32) return 0;   // (K = 512: 77 against 62 us for the static 64x64 tiling)
+  const double e128 = (double)t128 / (double)(agx::cdiv64(t128, 2 * cus) * 2 * cus);
+  const double e64 = (double)t64 / (double)(agx::cdiv64(t64, 4 * cus) * 4 * cus);
+  if (std::max(e128, e64) >= 0.92) return 0;
+  const long long per = t128 / 8 * kt / (wgs / 8);   // (lower bound of a workgroup's share)
+  if (per < 8 || per * 4 < kt) return 0;
+  if ((t128 / 8 + 1) * kt * (wgs / 8) >= (1ll << 31)) return 0;   // the kernel's share arithmetic is 32-bit
+  return wgs;
+}
 
 const int kWaveTiles[8][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {3, 1}, {1, 4}, {4, 1}, {3, 2}};
 
 // layout: 0 NN, 1 NT, 2 TN, -1 unknown (workspace bound: the larger split of the candidates)
-Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_floats, int layout = -1) {
+Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_floats, int layout = -1,
+               bool allow_sk = false) {
   Plan pl;
+  pl.sk_wgs = 0;
+  if (allow_sk) {
+    const int wgs = streamk_wgs(M, N, K, layout, force_cfg, force_splitk);
+    if (wgs > 0 && (int64_t)wgs * 128 * 128 <= ws_floats) {
+      pl.cfg = 0; pl.bm = pl.bn = 128; pl.wtm = pl.wtn = 1;
+      pl.tiles = agx::cdiv(M, 128) * agx::cdiv(N, 128);
+      pl.splitk = 1;
+      pl.kchunk = agx::cdiv(K > 0 ? K : 1, BK) * BK;
+      pl.sk_wgs = wgs;
+      return pl;
+    }
+  }
   const int cus = agx::num_cus();
   const int ktiles = agx::cdiv(K, BK);
   int cfg = force_cfg;
@@ -1591,6 +1766,8 @@ int gemm_prepare_device() {
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true, true>()));
+  // stream-K form of the plain 128x128 TN product
+  AGX_TRY((prepare_one<128, 128, 2, 2, true, false, true, false, 32, false, false, true>()));
   return AGX_OK;
 }
 }  // namespace agx
@@ -1598,8 +1775,12 @@ int gemm_prepare_device() {
 extern "C" int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K) {
   int sk = 1;
   for (int layout = -1; layout <= 0; ++layout) sk = std::max(sk, make_plan(M, N, K, -1, -1, INT64_MAX, layout).splitk);
-  return sk > 1 ? (int64_t)sk * M * N : 0;
+  // (a TN product that may run stream-K keeps one 128x128 partial tile per workgroup there)
+  const int64_t streamk = (int64_t)streamk_wgs(M, N, K, 2, -1, 0) * 128 * 128;
+  return std::max<int64_t>(sk > 1 ? (int64_t)sk * M * N : 0, streamk);
 }
+
+extern "C" int64_t agx_gemm_sk_flag_words(void) { return 2 * (int64_t)agx::num_cus() + 16; }
 
 extern "C" int agx_gemm_f32(void *stream, const agx_gemm_t *g) { return agx::gemm_run(stream, g, nullptr, nullptr); }
 
@@ -1682,14 +1863,20 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
       }
     }
   }
+  const bool vec = agx::aligned16(g->A) && agx::aligned16(g->B) && (g->lda % 4 == 0) && (g->ldb % 4 == 0);
+  // stream-K: plain or fused-optimizer TN products of callers that bring the hand-off words (zeroed once)
+  // (not with the fused optimizer: the finisher's update round trips are exposed - 191-200 against 169 us per launch)
+  const bool allow_sk = !opt && g->sk_flags && g->sk_flag_words >= agx_gemm_sk_flag_words() && vec && g->ws && agx::aligned16(g->ws) &&
+                        !raw_slabs && !(dual && dual->rows > 0) && !g->rowsq && g->interp_rows == 0 && !g->bias && !g->addrow &&
+                        !g->act && !g->mask && !g->accumulate && !g->rowscale && !g->col_scale;
   Plan pl = make_plan(g->M, g->N, g->K, g->force_cfg, g->rowsq ? 1 : g->force_splitk, g->ws ? g->ws_floats : 0,
-                      g->ta ? 2 : (g->tb ? 1 : 0));
+                      g->ta ? 2 : (g->tb ? 1 : 0), allow_sk);
   // A fused-optimizer product over a short K (batch < 128) is a memory-bound launch whose epilogue is its long pole:
   // the 64x64 instantiation (one 32x32 block per wave, operands prefetched, clamp-free interior path) also serves the
   // shapes whose tile count would choose 128x128 (wide critic, 20007 x 1024 x 96: 123 -> 9x us per launch).  No
   // split-K either way, so every element keeps the k order of the unfused launch.
   // (128x128 tiles there: wide critic 17.0 k instead of 20.3 k samples/s, profiles/r02_ab_wide_fused_tiles.txt)
-  if (opt && pl.cfg == 0 && pl.splitk == 1 && g->K <= 512 && g->force_cfg < 0)
+  if (opt && pl.cfg == 0 && !pl.sk_wgs && pl.splitk == 1 && g->K <= 512 && g->force_cfg < 0)
     pl = make_plan(g->M, g->N, g->K, 1, 1, g->ws ? g->ws_floats : 0, 2);
   // the fused epilogue exists for the LDS-tiled kernels without split-K; callers ask
   // gemm_can_fuse_opt first, so the product keeps the summation order of the unfused launch
@@ -1730,7 +1917,6 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
     p.interp_alpha = g->interp_alpha;
     p.to_ws = 1;
   }
-  const bool vec = agx::aligned16(g->A) && agx::aligned16(g->B) && (g->lda % 4 == 0) && (g->ldb % 4 == 0);
   hipStream_t st = agx::as_stream(stream);
   // algorithmic bytes: operands + result; a fused-optimizer product reads and writes weight and
   // slot (16 B) per updated element instead of storing the gradient (4 B): 4(MK + KN) + 16 MN
@@ -1742,7 +1928,11 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   //  NOT counted: SURVEY 8(d) prices the product and its optimizer traffic only; bench.py lists them apart)
   p.opt_tiles = pl.tiles;
   int rc;
-  if (opt && pl.cfg == 0)
+  if (pl.sk_wgs) {
+    p.sk_part = g->ws; p.sk_flags = g->sk_flags; p.sk_wgs = pl.sk_wgs; p.sk_nxcd = 8;
+    p.opt_tiles = pl.sk_wgs;
+    rc = launch<128, 128, 2, 2, true, false, true, false, 32, false, false, true>(st, p, pl.sk_wgs);
+  } else if (opt && pl.cfg == 0)
     rc = vec ? launch<128, 128, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
              : launch<128, 128, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
   else if (opt && g->K <= 512)   // short K (batch < 128): the epilogue's instruction stream is on the critical path

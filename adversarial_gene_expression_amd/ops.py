@@ -12,8 +12,9 @@ from ._dev import ptr
 
 def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0, slope=0.0, mask=None,
          out=None, accumulate=False, rowscale=None, rowsq=None, force_cfg=-1, force_splitk=0, use_ws=True,
-         interp=None, col_scale=None, col_shift=None):
-    """out[M, N] = epilogue(alpha * op(A) @ op(B)); leading dimensions are the row strides."""
+         interp=None, col_scale=None, col_shift=None, sk_flags=None):
+    """out[M, N] = epilogue(alpha * op(A) @ op(B)); leading dimensions are the row strides.
+    sk_flags: zero-initialised int32 device tensor of agx_gemm_sk_flag_words() words - allows the stream-K form."""
     lib = _lib.load()
     if out is None:
         out = _dev.empty((M, _dev.r4(N)))
@@ -41,6 +42,8 @@ def gemm(A, B, M, N, K, *, ta=0, tb=0, alpha=1.0, bias=None, addrow=None, act=0,
         ws = _dev.empty(max(wsf, 1))
         g.ws, g.ws_floats = ptr(ws), wsf
     g.force_cfg, g.force_splitk = force_cfg, force_splitk
+    if sk_flags is not None:
+        g.sk_flags, g.sk_flag_words = ptr(sk_flags), sk_flags.numel()
     if interp is not None:   # (rows, alpha): A = [real; fake], out gets the interpolated block too
         g.interp_rows, g.interp_alpha = interp[0], ptr(interp[1])
     _lib.check(lib.agx_gemm_f32(_dev.stream(), g), 'agx_gemm_f32')

@@ -117,10 +117,17 @@ typedef struct agx_gemm {
   const float *col_shift; /* after the bias, before the activation: v = v*col_scale[n] + col_shift[n] -    */
                         /* batch normalisation with folded statistics (agx_bn_fold).  The reference has */
                         /* no batch-norm (tf_utils.py:85-88): NULL on the parity path.                  */
+  uint32_t *sk_flags;   /* NULL, or >= agx_gemm_sk_flag_words() device words, ZEROED ONCE by the caller and  */
+  int32_t sk_flag_words;/* then left to the library: hand-off words of the stream-K form of a plain TN       */
+                        /* weight-gradient product (tile count that quantises badly over the CUs: the        */
+                        /* (tile, K-tile) space is dealt evenly over 2 x CUs workgroups, partial tiles meet  */
+                        /* in ws in a fixed order - bit-reproducible).  Word [2 x CUs] is a spin-timeout     */
+                        /* mark (stays 0).  Launches that share the words must not overlap.  NULL: never.    */
 } agx_gemm_t;
 int agx_gemm_f32(void *stream, const agx_gemm_t *p);
-/* Upper bound on the split-K scratch (floats) the heuristic may ask for. */
+/* Upper bound on the split-K / stream-K scratch (floats) the heuristic may ask for. */
 int64_t agx_gemm_ws_floats(int32_t M, int32_t N, int32_t K);
+int64_t agx_gemm_sk_flag_words(void);
 
 /* Optional batch-norm stage of a Dense layer (BASELINE.json north_star; the reference itself has none,
  * tf_utils.py:85-88, so nothing on the parity path calls these).

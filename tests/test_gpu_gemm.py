@@ -180,3 +180,34 @@ def test_gemm_interpolated_rows_by_linearity(gpu, R, N, K, cfg, sk):
     inter = A[:R] + alpha[:, None] * (A[R:] - A[:R])
     full = np.concatenate([A, inter]).astype(np.float64) @ B.astype(np.float64) + bias
     np.testing.assert_allclose(out.cpu().numpy()[:, :N], np.maximum(full, 0), atol=2e-5)
+
+
+@pytest.mark.parametrize('shape', [(18161, 256, 1536), (18161, 256, 1530), (18154, 256, 1030), (18161, 512, 1536)])
+def test_stream_k_weight_gradient_product(gpu, shape):
+    """Stream-K form of the TN weight-gradient product (gemm.hip SK: the (tile, K-tile) space dealt evenly over
+    2 x CUs workgroups, partial tiles handed over inside the launch): the 512-row dW_1 (284 tiles of 128x128 on 256
+    CUs), the same with a ragged K tail, the generator's output-layer gradient, a 512-wide first layer.  Against
+    NumPy float64 with the family's fma-chain bound; bit-identical on a second launch (fixed summation order);
+    every hand-off word back at zero afterwards and the spin-timeout word never set."""
+    from adversarial_gene_expression_amd import _dev, _lib, ops
+    lib = _lib.load()
+    M, N, K = shape
+    rs = np.random.RandomState(K)
+    A = rs.randn(K, M).astype(np.float32)
+    B = rs.randn(K, N).astype(np.float32)
+    nflag = int(lib.agx_gemm_sk_flag_words())
+    flags = torch.zeros(nflag, dtype=torch.int32, device='cuda')
+    Ad, Bd = _dev_mat(A), _dev_mat(B)
+    out1 = ops.gemm(Ad, Bd, M, N, K, ta=1, sk_flags=flags).clone()
+    torch.cuda.synchronize()
+    assert int(flags.abs().sum()) == 0
+    plain = ops.gemm(Ad, Bd, M, N, K, ta=1)                 # the static tiling, one k chain per element
+    out2 = ops.gemm(Ad, Bd, M, N, K, ta=1, sk_flags=flags)
+    torch.cuda.synchronize()
+    assert int(flags.abs().sum()) == 0
+    assert torch.equal(out1[:, :N], out2[:, :N])
+    assert not torch.equal(out1[:, :N], plain[:, :N])       # the stream-K kernel really ran (another summation order)
+    got = out1.cpu().numpy()[:, :N]
+    ref, bound = _ref(A, B, 1, 0), _bound(A, B, 1, 0)
+    assert np.all(np.abs(got - ref) <= 2e-6 * bound + 1e-30)
+    assert np.all(np.abs(plain.cpu().numpy()[:, :N] - ref) <= 2e-6 * bound + 1e-30)
