@@ -27,4 +27,13 @@ for b in 32 512; do
     rm -rf $d $d.log
   done
 done
+# 4. MFMA pipe busy per kernel of the 512-row iteration (and the correlation): its own counter pass
+d=$O/pmc_${tag}_mfma_512
+rm -rf $d
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $d -o p -- python3 bench.py --no-secondary --no-extra --no-cpu-baseline --steps 3 --warmup 1 --batch 512 --corr-n 20000 > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+python3 tools/pmc_summary.py mfma $(find $d -name '*counter_collection.csv' | head -1) > $O/${tag}_pmc_mfma_b512_corr.txt
+rm -rf $d $d.log
+for b in 32 512; do
+  python3 tools/pmc_summary.py traffic $O/${tag}_pmc_FETCH_SIZE_b$b.csv $O/${tag}_pmc_WRITE_SIZE_b$b.csv > $O/${tag}_pmc_traffic_b$b.txt
+done
 echo collected
