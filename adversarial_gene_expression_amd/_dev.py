@@ -68,30 +68,50 @@ def world():
 
 
 _native = {}
+_comm_streams = {}
 
 
 def native_comm():
-    """libagx's own RCCL communicator (agx_comm_*: collectives queued on the compute stream by the C library,
-    no c10d call per collective), used when AGX_NATIVE_COMM=1; None otherwise.  The 128-byte RCCL id travels
-    over the torch.distributed process group that launched the job."""
+    """libagx's own RCCL communicator (agx_comm_*: collectives queued by the C library on the streams it is
+    given, no c10d call per collective) or None.  Under torch.distributed it is used when the job's backend is
+    'nccl' (= RCCL) unless AGX_NATIVE_COMM=0, or whatever the backend with AGX_NATIVE_COMM=1; the 128-byte RCCL id
+    travels over the process group that launched the job.  Outside a distributed job AGX_DP_FORCE=1 yields a
+    ONE-rank communicator (every collective is the identity): the data-parallel code paths on one GPU, for tests."""
     import os
-    if os.environ.get('AGX_NATIVE_COMM') != '1':
-        return None
     import ctypes as C
     import torch.distributed as dist
-    key = (dist.get_world_size(), dist.get_rank())
+    env = os.environ.get('AGX_NATIVE_COMM')
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if distributed:
+        if env == '0' or (env != '1' and dist.get_backend() != 'nccl'):
+            return None
+        key = (dist.get_world_size(), dist.get_rank())
+    elif os.environ.get('AGX_DP_FORCE') == '1':
+        key = (1, 0)
+    else:
+        return None
     if key not in _native:
         lib = _lib.load()
         device()
         buf = (C.c_char * 128)()
-        if dist.get_rank() == 0:
+        if key[1] == 0:
             _lib.check(lib.agx_comm_unique_id(buf), 'agx_comm_unique_id')
         box = [bytes(buf)]
-        dist.broadcast_object_list(box, src=0)
+        if distributed:
+            dist.broadcast_object_list(box, src=0)
         comm = C.c_void_p()
         _lib.check(lib.agx_comm_init(C.create_string_buffer(box[0], 128), key[0], key[1], C.byref(comm)), 'agx_comm_init')
         _native[key] = comm
     return _native[key]
+
+
+def comm_stream():
+    """The stream the overlapped data-parallel exchange runs on (one per device, kept)."""
+    dev = device()
+    st = _comm_streams.get(dev.index)
+    if st is None:
+        st = _comm_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return st
 
 
 def allreduce_sum(t):

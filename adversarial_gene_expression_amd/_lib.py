@@ -111,6 +111,29 @@ class IterArgs(C.Structure):
     ]
 
 
+AGX_MAX_DP_PIECES = 16
+
+
+class DpNet(C.Structure):
+    _fields_ = [
+        ('n_pieces', C.c_int32),
+        ('rows', C.c_int32 * (AGX_MAX_DP_PIECES + 1)),
+        ('start', C.c_int64 * AGX_MAX_DP_PIECES),
+        ('per', C.c_int64 * AGX_MAX_DP_PIECES),
+        ('slot0', C.c_void_p), ('slot1', C.c_void_p),
+        ('lr', C.c_float),
+    ]
+
+
+class DpArgs(C.Structure):
+    _fields_ = [
+        ('disc', DpNet), ('gen', DpNet),
+        ('opt_kind', C.c_int32),
+        ('rho', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+        ('lr_t_host', C.c_void_p),
+    ]
+
+
 class RngSeg(C.Structure):
     _fields_ = [('out', C.c_void_p), ('n', C.c_int64), ('sub_offset', C.c_uint64), ('normal', C.c_int32),
                 ('skip', C.c_int64)]
@@ -220,6 +243,7 @@ SIGNATURES = {
     'agx_cgan_iter_set_lr': (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
     'agx_cgan_iter_eager': (C.c_int, [_vp, _vp, C.POINTER(IterArgs), _vp, _i32, _vp, _vp, _u64, _vp, C.POINTER(_i64)]),
     'agx_cgan_iter_destroy': (C.c_int, [_vp]),
+    'agx_cgan_dp_iteration': (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(DpArgs), _vp, _i32, _vp, _vp, _u64]),
     'agx_comm_unique_id': (C.c_int, [_vp]),
     'agx_comm_init': (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     'agx_comm_destroy': (C.c_int, [_vp]),

@@ -66,6 +66,7 @@ struct agx_cgan {
   uint32_t *skflags = nullptr;              // stream-K hand-off words (zeroed at bind, self-cleaning)
   int skflag_words = 0;
   bool use_sk = false;                      // set while the segments of a data-parallel iteration are recorded
+  bool skip_big = false;                    // split == 3: the largest weight-gradient product is launched by agx_cgan_dp_iteration
   int64_t ws_floats_total = 0;
 };
 
@@ -442,6 +443,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   agx::TnJobs tn;
   tn.n = 0;
   auto weight_grad = [&](int l) -> int {
+    if (l == 0 && h->skip_big) return AGX_OK;   // launched in row chunks by agx_cgan_dp_iteration (big_grad_chunk)
     const float *in = l == 0 ? h->X : h->A[l];
     const int ldin = l == 0 ? ldx : h->ldh[l];
     if (l > 0 && tn_fuse() && agx::tn_job_ok(m.dims[l], m.dims[l + 1], R)) {
@@ -512,12 +514,15 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     // which must then follow the delta product that still reads W_out (same stream, after it)
     const bool fused = fo && l == Lg;
     auto weight_grad = [&]() -> int {
+      if (l == Lg && h->skip_big) return AGX_OK;   // (see critic_core)
       Gemm g(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l], gm.dims[l + 1], B);
       g.id(l == Lg ? AGX_K_GEN_DW_OUT : AGX_K_GEN_DW_HID);
       if (fused) g.opt(fo);
       return g.run(st);
     };
-    if (!fused && tn_fuse() && agx::tn_job_ok(gm.dims[l], gm.dims[l + 1], B)) {
+    if (l == Lg && h->skip_big) {
+      // launched in row chunks by agx_cgan_dp_iteration
+    } else if (!fused && tn_fuse() && agx::tn_job_ok(gm.dims[l], gm.dims[l + 1], B)) {
       // a few 32x32 tiles over K = B rows: rides the small-gradient launch at the end of the step
       tn.job[tn.n++] = agx::TnJobs::Job{in, dout, h->gg + gm.w_off[l], ldin, lddout, gm.ldw[l], gm.dims[l],
                                         gm.dims[l + 1], B};
@@ -703,6 +708,11 @@ struct agx_iter_graph {
   bool chainx = false; // real rows are staged into both stacked-input buffers (chain_input)
   const float *aug_mask = nullptr, *aug_noise_real = nullptr;   // augmentation of the staged real rows (trace constants)
   agx::LrTable lrs;    // Adam: step sizes for the next replay (agx_cgan_iter_set_lr)
+  int split = 0, B_global = 0;
+  // agx_cgan_dp_iteration: one event per row chunk of the large product + "exchange of the step done"
+  hipEvent_t ev_chunk[AGX_MAX_DP_PIECES] = {};
+  hipEvent_t ev_done = nullptr;
+  bool have_events = false;
 };
 
 namespace {
@@ -830,8 +840,9 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   // alternate between the two stacked-input buffers
   const bool chainx = seg < 0 && fuse_d && rest_d && chain_input(h, a);
   float *Xb[2] = {h->Xbuf[0], chainx ? h->Xbuf[1] : h->Xbuf[0]};
-  struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; h->use_sk = false; } } restore{h};
-  h->use_sk = a->split == 2;
+  struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; h->use_sk = false; h->skip_big = false; } } restore{h};
+  h->use_sk = a->split >= 2;
+  h->skip_big = a->split == 3;
   // fake rows of step k (k == nbc: the generator step's rows [0,B)) into buffer k&1; with_cov: also
   // the covariate columns of the step's rows from the CURRENT embedding tables (same launch)
   auto place_fake = [&](int k, hipStream_t s, bool with_cov = false) -> int {
@@ -875,7 +886,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
       AGX_TRY(critic_core(h, st, h->scat, B, Bg, h->abuf + (size_t)k * B, a->gp_weight,
                           a->disc_losses ? a->disc_losses : h->losslog + 4 * k, fuse_d ? &dk : nullptr));
     }
-    if (in_seg(k + 1) && a->split != 2) {
+    if (in_seg(k + 1) && a->split < 2) {
       if (adam) AGX_TRY(agx::opt_adam_dev_lr(st, h->dp, h->dg, a->disc_m, a->disc_v, dm.n_flat, h->lrdev + k, a->beta1, a->beta2, a->eps));
       else if (fuse_d && rest_d) {}   // updated by the layer-1 product's launch
       else if (fuse_d) AGX_TRY(agx::opt_rmsprop_hole(st, h->dp, h->dg, a->disc_rms, dm.n_flat, dhole_lo, dhole_hi, a->lr_disc, a->rho, a->eps));
@@ -888,7 +899,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc,
                      fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));
   }
-  if (in_seg(nbc + 1) && a->split != 2) {
+  if (in_seg(nbc + 1) && a->split < 2) {
     if (adam) AGX_TRY(agx::opt_adam_dev_lr(st, h->gp, h->gg, a->gen_m, a->gen_v, gm0.n_flat, h->lrdev + nbc, a->beta1, a->beta2, a->eps));
     else if (fuse_g && rest) {}     // updated by the output-layer product's launch
     else if (fuse_g) AGX_TRY(agx::opt_rmsprop_hole(st, h->gp, h->gg, a->gen_rms, gm0.n_flat, ghole_lo, ghole_hi, a->lr_gen, a->rho, a->eps));
@@ -909,8 +920,8 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
                 "agx_cgan_iter_capture: rows [%d, %d) outside the global batch %d", a->row_lo, a->row_lo + a->B, a->B_global);
   AGX_CHECK_ARG(a->B_global != 0 || a->row_lo == 0, "agx_cgan_iter_capture: row_lo without B_global");
   AGX_CHECK_ARG(a->opt_kind == 0 || a->opt_kind == 1, "agx_cgan_iter_capture: opt_kind %d", a->opt_kind);
-  AGX_CHECK_ARG(a->split >= 0 && a->split <= 2, "agx_cgan_iter_capture: split %d", a->split);
-  AGX_CHECK_ARG(a->split == 2 || (a->opt_kind == 1 ? (a->disc_m && a->disc_v && a->gen_m && a->gen_v) : (a->disc_rms && a->gen_rms)),
+  AGX_CHECK_ARG(a->split >= 0 && a->split <= 3, "agx_cgan_iter_capture: split %d", a->split);
+  AGX_CHECK_ARG(a->split >= 2 || (a->opt_kind == 1 ? (a->disc_m && a->disc_v && a->gen_m && a->gen_v) : (a->disc_rms && a->gen_rms)),
                 "agx_cgan_iter_capture: optimizer slots missing");
   AGX_CHECK_ARG(!a->aug_mask_disc || (a->aug_noise_fake && a->aug_noise_real), "agx_cgan_iter_capture: critic aug noise missing");
   AGX_CHECK_ARG(!a->aug_mask_gen || a->aug_noise_gen, "agx_cgan_iter_capture: generator aug noise missing");
@@ -924,12 +935,14 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   AGX_CHECK_ARG(g, "agx_cgan_iter_capture: out of host memory");
   g->h = h; g->B = a->B; g->nb_critic = a->nb_critic;
   g->snap = !a->split && !a->disc_losses && !a->gen_losses;
-  g->adam = a->opt_kind == 1 && a->split != 2;   // split == 2: the caller's optimizer launches take their step size from the host
+  g->adam = a->opt_kind == 1 && a->split < 2;   // split >= 2: the caller's optimizer launches take their step size from the host
+  g->split = a->split;
+  g->B_global = a->B_global > 0 ? a->B_global : a->B;
   g->chainx = chain_input(h, a);
   g->aug_mask = a->aug_mask_disc;
   g->aug_noise_real = a->aug_noise_real;
   g->lrs.n = 0;
-  const int nseg = a->split == 2 ? a->nb_critic + 1 : (a->split ? a->nb_critic + 2 : 1);
+  const int nseg = a->split >= 2 ? a->nb_critic + 1 : (a->split ? a->nb_critic + 2 : 1);
   for (int s = 0; s < nseg; ++s) {
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) {
@@ -1054,12 +1067,105 @@ extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_a
   return AGX_OK;
 }
 
+namespace {
+// rows [r0, r1) of a step's largest weight-gradient product (critic: dW_1 = [a_0(real); a_0(fake); e_0]^T D_1 over the
+// 3B stacked rows; generator: dW_out = h_L^T dX over its B rows), same operands as critic_core / gen_core use
+int big_grad_chunk(agx_cgan *h, hipStream_t st, bool gen, int r0, int r1, int B, int gen_row0) {
+  const agx_mlp_desc_t &m = gen ? h->cfg.gen : h->cfg.disc;
+  const int l = gen ? m.n_layers - 1 : 0;
+  const float *in = gen ? h->gh[l] + (size_t)gen_row0 * h->ldgh[l] : h->Xbuf[0];
+  const int ldin = gen ? h->ldgh[l] : h->ldx;
+  const float *dl = gen ? h->Xbuf[0] + (size_t)B * h->ldx : h->D[1];
+  const int ldd = gen ? h->ldx : h->ldh[1];
+  float *out = (gen ? h->gg : h->dg) + m.w_off[l];
+  Gemm g(h, in + r0, ldin, 1, dl, ldd, 0, out + (size_t)r0 * m.ldw[l], m.ldw[l], r1 - r0, m.dims[l + 1], gen ? B : 3 * B);
+  return g.id(gen ? AGX_K_GEN_DW_OUT : AGX_K_DISC_DW_IN).sk(true).run(st);
+}
+
+int check_dp_net(const agx_dp_net_t &n, const agx_mlp_desc_t &m, int l, int nranks, int opt_kind, const char *name) {
+  AGX_CHECK_ARG(n.n_pieces >= 1 && n.n_pieces <= AGX_MAX_DP_PIECES, "%s: n_pieces %d", name, n.n_pieces);
+  AGX_CHECK_ARG(n.slot0 && (opt_kind == 0 || n.slot1), "%s: optimizer slots missing", name);
+  AGX_CHECK_ARG(n.rows[0] == 0 && n.rows[n.n_pieces] == m.dims[l], "%s: row chunks must cover [0, %d)", name, m.dims[l]);
+  const int64_t big_lo = m.w_off[l];
+  int64_t at = 0;
+  for (int c = 0; c < n.n_pieces; ++c) {
+    AGX_CHECK_ARG(n.rows[c + 1] > n.rows[c] && (n.rows[c] % 4) == 0, "%s: row chunk %d = [%d, %d)", name, c, n.rows[c], n.rows[c + 1]);
+    AGX_CHECK_ARG(n.start[c] == at && n.per[c] > 0 && (n.start[c] % 4) == 0 && (n.per[c] % 4) == 0,
+                  "%s: piece %d = (%lld, %lld) does not continue at %lld / is not 16-B aligned", name, c, (long long)n.start[c],
+                  (long long)n.per[c], (long long)at);
+    at += n.per[c] * nranks;
+    // complete once chunk c is: nothing of it lies behind the rows computed so far (the last piece: everything)
+    AGX_CHECK_ARG(c == n.n_pieces - 1 || at <= big_lo + (int64_t)n.rows[c + 1] * m.ldw[l],
+                  "%s: piece %d ends at %lld, behind row %d of the large kernel", name, c, (long long)at, n.rows[c + 1]);
+  }
+  AGX_CHECK_ARG(at >= m.n_flat + 64, "%s: pieces cover %lld floats < n_flat + 64 loss slots", name, (long long)at);
+  return AGX_OK;
+}
+}  // namespace
+
+extern "C" int agx_cgan_dp_iteration(agx_iter_graph_t *g, void *stream, void *comm_stream, agx_comm_t *comm,
+                                     const agx_dp_args_t *a, const float *x, int32_t ldx, const int32_t *cat,
+                                     const float *num, uint64_t rng_offset) {
+  AGX_CHECK_ARG(g && a && comm && x, "agx_cgan_dp_iteration: null argument");
+  AGX_CHECK_ARG(g->split == 3 && g->nseg == g->nb_critic + 1, "agx_cgan_dp_iteration: the graph must be captured with split = 3");
+  AGX_CHECK_ARG(comm_stream && stream != comm_stream, "agx_cgan_dp_iteration: the exchange needs a (non-default) stream of its own");
+  AGX_CHECK_ARG(a->opt_kind == 0 || (a->opt_kind == 1 && a->lr_t_host), "agx_cgan_dp_iteration: opt_kind %d", a->opt_kind);
+  agx_cgan *h = g->h;
+  const int nranks = agx_comm_size(comm), rank = agx_comm_rank(comm);
+  const int nbc = g->nb_critic, B = g->B;
+  AGX_TRY(check_dp_net(a->disc, h->cfg.disc, 0, nranks, a->opt_kind, "agx_cgan_dp_iteration (critic)"));
+  AGX_TRY(check_dp_net(a->gen, h->cfg.gen, h->cfg.gen.n_layers - 1, nranks, a->opt_kind, "agx_cgan_dp_iteration (generator)"));
+  hipStream_t cs = agx::as_stream(stream), ms = agx::as_stream(comm_stream);
+  if (!g->have_events) {
+    for (int c = 0; c < AGX_MAX_DP_PIECES; ++c) AGX_HIP(hipEventCreateWithFlags(&g->ev_chunk[c], hipEventDisableTiming));
+    AGX_HIP(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
+    g->have_events = true;
+  }
+  AGX_TRY(agx_cgan_iter_stage(g, stream, x, ldx, cat, num, rng_offset));
+  for (int s = 0; s <= nbc; ++s) {
+    const bool gen = s == nbc;
+    const agx_dp_net_t &n = gen ? a->gen : a->disc;
+    const agx_mlp_desc_t &m = gen ? h->cfg.gen : h->cfg.disc;
+    float *params = gen ? h->gp : h->dp, *grads = gen ? h->gg : h->dg;
+    if (s > 0) AGX_HIP(hipStreamWaitEvent(cs, g->ev_done, 0));   // the parameters of step s - 1 are in place
+    AGX_HIP(hipGraphLaunch(g->exec[s], cs));
+    for (int c = 0; c < n.n_pieces; ++c) {
+      AGX_TRY(big_grad_chunk(h, cs, gen, n.rows[c], n.rows[c + 1], B, nbc * B));
+      AGX_HIP(hipEventRecord(g->ev_chunk[c], cs));
+    }
+    for (int c = 0; c < n.n_pieces; ++c) {
+      const int64_t per = n.per[c], lo = n.start[c] + (int64_t)rank * per;
+      AGX_HIP(hipStreamWaitEvent(ms, g->ev_chunk[c], 0));
+      AGX_TRY(agx_comm_reduce_scatter_sum(comm, ms, grads + n.start[c], grads + lo, per));
+      const int64_t n_upd = std::max<int64_t>(0, std::min<int64_t>(lo + per, m.n_flat) - lo);
+      if (n_upd > 0) {
+        if (a->opt_kind == 1)
+          AGX_TRY(agx_opt_adam(ms, params + lo, grads + lo, n.slot0 + lo, n.slot1 + lo, n_upd, a->lr_t_host[s], a->beta1, a->beta2,
+                               a->eps, 1.f));
+        else
+          AGX_TRY(agx_opt_rmsprop(ms, params + lo, grads + lo, n.slot0 + lo, n_upd, n.lr, a->rho, a->eps, 1.f));
+      }
+      if (lo + per > m.n_flat) {   // loss slots (+ padding): the reduced values themselves are what travels back
+        const int64_t from = std::max<int64_t>(lo, m.n_flat);
+        AGX_HIP(hipMemcpyAsync(params + from, grads + from, (size_t)(lo + per - from) * sizeof(float), hipMemcpyDeviceToDevice, ms));
+      }
+      AGX_TRY(agx_comm_all_gather(comm, ms, params + lo, params + n.start[c], per));
+    }
+    AGX_HIP(hipEventRecord(g->ev_done, ms));
+  }
+  AGX_HIP(hipStreamWaitEvent(cs, g->ev_done, 0));
+  return AGX_OK;
+}
+
 extern "C" int agx_cgan_iter_destroy(agx_iter_graph_t *g) {
   if (g) {
     for (int s = 0; s < AGX_MAX_ITER_SEGS; ++s) {
       if (g->exec[s]) (void)hipGraphExecDestroy(g->exec[s]);
       if (g->graph[s]) (void)hipGraphDestroy(g->graph[s]);
     }
+    for (int c = 0; c < AGX_MAX_DP_PIECES; ++c)
+      if (g->ev_chunk[c]) (void)hipEventDestroy(g->ev_chunk[c]);
+    if (g->ev_done) (void)hipEventDestroy(g->ev_done);
     delete g;
   }
   return AGX_OK;

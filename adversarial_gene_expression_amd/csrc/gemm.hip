@@ -1623,7 +1623,7 @@ struct Plan {
 
 // Stream-K applies (see gemm_kernel): aligned TN product, heuristic tile choice, no split-K, enough 128x128 tiles to
 // give every XCD work but a tile count that leaves the best static tiling below 92 % of its rounds, and shares of
-// >= 8 K-tiles that are no shorter than a quarter of a tile's K range (<= 5 partials per tile).
+// >= 8 K-tiles that are no shorter than half a tile's K range (<= 3 partials per tile).
 int streamk_wgs(int M, int N, int K, int layout, int force_cfg, int force_splitk) {
   static const bool off = getenv("AGX_NO_STREAMK") != nullptr;
   if (off || layout != 2 || force_cfg >= 0 || force_splitk > 0) return 0;
@@ -1638,7 +1638,9 @@ int streamk_wgs(int M, int N, int K, int layout, int force_cfg, int force_splitk
   const double e64 = (double)t64 / (double)(agx::cdiv64(t64, 4 * cus) * 4 * cus);
   if (std::max(e128, e64) >= 0.92) return 0;
   const long long per = t128 / 8 * kt / (wgs / 8);   // (lower bound of a workgroup's share)
-  if (per < 8 || per * 4 < kt) return 0;
+  // (shares of at least half a tile's K range, i.e. <= 3 partials per tile: 9088 x 256 x 1536 with four per tile ran
+  //  105 against 97 us for the static tiling, 18161 x 256 x 1536 with two to three 162 against 179 us)
+  if (per < 8 || per * 2 < kt) return 0;
   if ((t128 / 8 + 1) * kt * (wgs / 8) >= (1ll << 31)) return 0;   // the kernel's share arithmetic is 32-bit
   return wgs;
 }

@@ -49,6 +49,7 @@ extern "C" int64_t agx_sizeof(int32_t which) {
     case 5: return sizeof(agx_cgan_config_t);
     case 6: return sizeof(agx_step_args_t);
     case 7: return sizeof(agx_iter_args_t);
+    case 8: return sizeof(agx_dp_args_t);
     default: return -1;
   }
 }

@@ -544,8 +544,8 @@ class _Pair:
         a.B, a.nb_critic, a.gp_weight = B, nb_critic, gp_weight
         a.lr_disc, a.lr_gen = disc_opt.learning_rate, gen_opt.learning_rate
         a.eps = disc_opt.epsilon
-        if int(split) == 2:
-            pass     # no optimizer launch inside the segments: the slots stay with the caller (_dp_update)
+        if int(split) >= 2:
+            pass     # no optimizer launch inside the segments: the slots stay with the caller (_dp_update / the C driver)
         elif type(disc_opt) is Adam:
             a.opt_kind, a.beta1, a.beta2 = 1, disc_opt.beta_1, disc_opt.beta_2
             sd, sg = disc_opt.slot(disc), gen_opt.slot(gen)
@@ -707,6 +707,61 @@ def _exchange_pieces(net, world, chunks=0):
     bounds = [0] + [(off + r * ld) // q * q for r in _exchange_rows(net, chunks)[1:-1]] + [total]
     bounds = sorted(set(bounds))
     return [(a, (b - a) // world) for a, b in zip(bounds[:-1], bounds[1:])]
+
+
+def _exchange_plan(net, world, chunks):
+    """(rows, pieces) of the overlapped exchange: row chunk c of the largest weight-gradient product and the piece of
+    the flat buffers that is complete - and travels - once that chunk is (same cuts as `_exchange_pieces`)."""
+    rows, pieces = _exchange_rows(net, chunks), _exchange_pieces(net, world, chunks)
+    if len(pieces) != len(rows) - 1:        # degenerate cuts: one chunk, one piece
+        rows, pieces = [0, rows[-1]], _exchange_pieces(net, world, 0)
+    return rows, pieces
+
+
+def _dp_native_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, gp_weight, aug_d, aug_g, Bg, row_lo, comm):
+    """One data-parallel loop iteration driven by the library (agx_cgan_dp_iteration): per optimizer step the
+    gradient segment, then the largest weight-gradient product in row chunks on the compute stream while a
+    second stream reduce-scatters, updates and all-gathers the pieces that are complete - no Python between
+    the steps.  Same exchange layout and results as `_dp_update`."""
+    lib = _lib.load()
+    world, rank = _world()
+    B = x.shape[0]
+    pair = _pair(gen, disc, B, nb_critic + 1)
+    g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, gp_weight, _rng.seed, aug_d, aug_g,
+                             batch_global=Bg, row_lo=row_lo, split=3)
+    a = _lib.DpArgs()
+    keep = []
+    for net, opt, dst in ((disc, disc_opt, a.disc), (gen, gen_opt, a.gen)):
+        rows, pieces = _exchange_plan(net, world, _dp_chunks())
+        if len(pieces) > _lib.AGX_MAX_DP_PIECES:
+            raise ValueError('AGX_DP_CHUNKS: at most %d pieces' % _lib.AGX_MAX_DP_PIECES)
+        dst.n_pieces = len(pieces)
+        for i, r in enumerate(rows):
+            dst.rows[i] = r
+        for i, (st, per) in enumerate(pieces):
+            dst.start[i], dst.per[i] = st, per
+        if type(opt) is Adam:
+            sl = opt.slot(net)
+            dst.slot0, dst.slot1 = ptr(sl[0]), ptr(sl[1])
+        else:
+            dst.slot0, dst.lr = ptr(opt.slot(net)), opt.learning_rate
+    if type(disc_opt) is Adam:
+        a.opt_kind, a.beta1, a.beta2 = 1, disc_opt.beta_1, disc_opt.beta_2
+        lrs = _adam_step_sizes(gen, disc, gen_opt, disc_opt, nb_critic)
+        keep.append(lrs)
+        a.lr_t_host = _lib.C.cast(lrs, _lib.C.c_void_p)
+    else:
+        a.rho = disc_opt.rho
+    a.eps = disc_opt.epsilon
+    cs = _dev.comm_stream()
+    cs.wait_stream(torch.cuda.current_stream())      # (first use: everything queued so far precedes the exchange)
+    _lib.check(lib.agx_cgan_dp_iteration(g, _dev.stream(), cs.cuda_stream, comm, a, ptr(x), x.stride(0), ptr(cc), ptr(nc),
+                                         _rng.offset), 'agx_cgan_dp_iteration')
+    _rng.offset += int(lib.agx_cgan_iter_rng_draws(g))
+    disc_opt.iterations += nb_critic
+    gen_opt.iterations += 1
+    d_loss = _reduced_loss(disc, 2) if nb_critic > 0 else None
+    return d_loss, _reduced_loss(gen, 0)
 
 
 def _dp_update(net, opt):
@@ -933,6 +988,11 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
         rows = (row_lo, row_lo + B) if world > 1 else None
         aug_d = _aug_constants('disc', (weakref.ref(gen), weakref.ref(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
         aug_g = _aug_constants('gen', (weakref.ref(gen), weakref.ref(disc), Bg, row_lo, B), p_aug, norm_scale, Bg, gen.x_dim, rows)
+    # data parallel over RCCL (or AGX_DP_FORCE=1 on one GPU): the library drives the steps and overlaps the exchange
+    comm = _dev.native_comm() if os.environ.get('AGX_DP_OVERLAP', '1') != '0' else None
+    if comm is not None and nb_critic > 0:
+        return _dp_native_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, grad_penalty_weight, aug_d, aug_g,
+                                    Bg, row_lo, comm)
     g = pair.iteration_graph(gen, disc, gen_opt, disc_opt, B, nb_critic, grad_penalty_weight, _rng.seed, aug_d, aug_g,
                              batch_global=Bg, row_lo=row_lo, split=2 if world > 1 else 0)
     if type(disc_opt) is Adam and world == 1:

@@ -162,6 +162,21 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True)
 
     dbg = (lambda m: print('[bench rank %d] %s' % (rank, m), file=sys.stderr, flush=True)) if os.environ.get('AGX_BENCH_DEBUG') else (lambda m: None)
     dbg('models built')
+    if world > 1 and dist.get_backend() == 'nccl' and os.environ.get('AGX_DP_OVERLAP', '1') != '0':
+        # The library-driven overlapped exchange (agx_cgan_dp_iteration over libagx's own RCCL communicator) is the
+        # default under RCCL.  It has only ever run with ONE rank on the builder's one-GPU boxes: if any rank fails to
+        # bring it up, ALL ranks fall back together to the c10d-driven exchange (tf_utils._dp_update).
+        ok = 1.0
+        try:
+            iteration(next_i())
+            torch.cuda.synchronize()
+        except Exception as e:          # noqa: BLE001 - anything: the fall-back must be collective
+            print('[bench rank %d] overlapped exchange failed (%r): falling back' % (rank, e), file=sys.stderr, flush=True)
+            ok = 0.0
+        t = torch.tensor([ok], device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if float(t.item()) < 1.0:
+            os.environ['AGX_DP_OVERLAP'] = '0'
     iteration(next_i())                        # first call: workspace, graph capture
     sync()
     nprobe = 3

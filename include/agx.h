@@ -430,7 +430,9 @@ typedef struct agx_iter_args {
   /* WITHOUT optimizer launches (the caller reduce-scatters the gradients, updates its 1/R shard of */
   /* the parameters and all-gathers them between segments; no optimizer slots needed here);         */
   /* disc_losses / gen_losses (device [4]) redirect the loss scalars, e.g. into slots that ride the */
-  /* gradient all-reduce.                                                                           */
+  /* gradient all-reduce.  split = 3: as 2, and the LARGEST weight-gradient product of each step      */
+  /* (critic W_1, generator W_out) is left out of its segment: agx_cgan_dp_iteration launches it in  */
+  /* row chunks and exchanges chunk c on a second stream while chunk c+1 multiplies.                 */
   int32_t B_global, row_lo, split;
   float *disc_losses, *gen_losses;
   /* optimizer of the captured iteration: 0 = RMSprop (fields above), 1 = Keras-v2 Adam on both nets   */
@@ -494,6 +496,40 @@ int agx_comm_allreduce_sum(agx_comm_t *c, void *stream, void *buf, int64_t n, in
 int agx_comm_reduce_scatter_sum(agx_comm_t *c, void *stream, const float *in, float *out, int64_t n_per_rank);
 /* out[r*n_per_rank ..] = rank r's in[0..n_per_rank) */
 int agx_comm_all_gather(agx_comm_t *c, void *stream, const float *in, float *out, int64_t n_per_rank);
+
+
+/* ---- data-parallel iteration with the exchange overlapped, driven from this library (no reference ----
+ *      counterpart: tf_utils.py:316-323 is one process on one GPU).  `g` was captured with split = 3.  Per
+ *      optimizer step: segment s on `stream` (everything but the largest weight-gradient product), then that
+ *      product in n_pieces row chunks rows[c] .. rows[c+1] (multiples of 4 rows) on `stream`, an event after
+ *      each; on `comm_stream`, per chunk as soon as its event has fired: in-place reduce-scatter of piece c of
+ *      the flat gradient buffer ([start[c], start[c] + per[c] * nranks): rank r owns [start + r per, + per)),
+ *      the optimizer on the own share (slots of other shares are never touched), the loss scalars behind the
+ *      gradients copied across, in-place all-gather of the piece of the parameter buffer.  The next segment
+ *      waits for the last all-gather.  Pieces must tile [0, total), total >= n_flat + 64 loss slots, every
+ *      start and per a multiple of 4 floats, and piece c must be complete once chunk c is (it ends at or
+ *      before flat offset w_off + rows[c+1] * ldw of the largest kernel; the LAST piece holds everything
+ *      behind it).  RMSprop (opt_kind 0) or Adam (1; lr_t_host = nb_critic + 1 bias-corrected step sizes).
+ *      Both buffers of a net must extend to `total` floats.  Nothing is allocated; events are created at the
+ *      first call on a graph.  With one rank every collective is the identity (testing).                  */
+#define AGX_MAX_DP_PIECES 16
+typedef struct agx_dp_net {
+  int32_t n_pieces;
+  int32_t rows[AGX_MAX_DP_PIECES + 1];
+  int64_t start[AGX_MAX_DP_PIECES];
+  int64_t per[AGX_MAX_DP_PIECES];
+  float *slot0, *slot1;     /* RMSprop: rms, NULL; Adam: m, v (flat, parameter layout) */
+  float lr;                 /* RMSprop learning rate                                    */
+} agx_dp_net_t;
+typedef struct agx_dp_args {
+  agx_dp_net_t disc, gen;
+  int32_t opt_kind;
+  float rho, beta1, beta2, eps;
+  const float *lr_t_host;
+} agx_dp_args_t;
+int agx_cgan_dp_iteration(agx_iter_graph_t *g, void *stream, void *comm_stream, agx_comm_t *comm,
+                          const agx_dp_args_t *a, const float *x, int32_t ldx, const int32_t *cat,
+                          const float *num, uint64_t rng_offset);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ def test_struct_sizes_match_header_layout():
     # every mirror against the size the library itself was compiled with
     lib = _lib.load()
     mirrors = [_lib.GemmDesc, _lib.EmbedDesc, _lib.SmallGrads, _lib.RngSeg, _lib.MlpDesc, _lib.CganConfig,
-               _lib.StepArgs, _lib.IterArgs]
+               _lib.StepArgs, _lib.IterArgs, _lib.DpArgs]
     for i, m in enumerate(mirrors):
         assert lib.agx_sizeof(i) == ctypes.sizeof(m), (m.__name__, lib.agx_sizeof(i), ctypes.sizeof(m))
     assert lib.agx_sizeof(len(mirrors)) == -1
