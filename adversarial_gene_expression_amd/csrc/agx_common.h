@@ -85,6 +85,7 @@ int critic_tail(void *stream, int mode, const TailArgs &a);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused
 // epilogue, without split-K (then fused and unfused runs sum in the same order: bit-identical)
 bool gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats);
+int colstats_scratch_init();   // corr.hip: address of the static scratch of agx_colstats_noalloc on the current device
 // Loss-log snapshot done by the last small-gradient launch of a captured iteration: n floats from
 // src to the address stored at *dst_slot (left there by iter_stage; NULL address: no copy).
 struct LossCopy {

@@ -317,6 +317,13 @@ int sums_finish(hipStream_t st, const double *part, int nblocks, int nvals, doub
 
 }  // namespace
 
+// agx_init resolves the scratch address of the device it initialises, so that the first agx_colstats_noalloc call
+// on that device makes no runtime query (a caller may already be capturing a graph)
+int agx::colstats_scratch_init() {
+  double *p = nullptr;
+  return scratch_for_current_device(&p);
+}
+
 extern "C" int64_t agx_colstats_ws_doubles(int32_t N, int32_t G) {
   if (N <= 0 || G <= 0) return 0;
   return (int64_t)2 * G * colstats_chunks(N, G);

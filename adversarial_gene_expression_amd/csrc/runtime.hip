@@ -36,6 +36,7 @@ extern "C" int agx_init(int device) {
   }
   g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   AGX_TRY(agx::gemm_prepare_device());
+  AGX_TRY(agx::colstats_scratch_init());
   return AGX_OK;
 }
 

@@ -297,7 +297,10 @@ int agx_colstats(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G
  * in a static device array of AGX_COLSTATS_NOALLOC_DOUBLES doubles (2 MiB per GPU, held until the
  * process ends); G <= AGX_COLSTATS_NOALLOC_MAX_G, larger G is rejected with AGX_E_INVALID.  Same
  * kernels and chunking as agx_colstats => bit-identical mean / std.  Calls that overlap on one GPU
- * (different streams or threads) share that array and RACE: serialise them.                      */
+ * (different streams or threads) share that array and RACE: serialise them.  agx_init(device)     *
+ * resolves the array's address, so a call on an initialised device makes no runtime query and may  *
+ * be recorded into a graph (a device that was never initialised resolves it at its first call:     *
+ * make that call outside a capture).                                                               */
 #define AGX_COLSTATS_NOALLOC_MAX_G 65536
 #define AGX_COLSTATS_NOALLOC_DOUBLES 262144
 int agx_colstats_noalloc(void *stream, const float *x, int32_t ldx, int32_t N, int32_t G,

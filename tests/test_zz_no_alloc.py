@@ -37,6 +37,27 @@ def test_no_alloc_colstats_matches_workspace_variant(gpu):
         ref = x[:, :G].double()
         np.testing.assert_allclose(m1.cpu().numpy(), ref.mean(0).cpu().numpy(), rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(s1.cpu().numpy(), ref.std(0, unbiased=False).cpu().numpy(), rtol=1e-6)
+    # no device memory is taken or returned by the call, and it can be recorded into a graph (the address of the
+    # static scratch was resolved by agx_init): replaying the graph gives the same statistics
+    N, G, ld = 227, 1076, 1076
+    x = torch.randn(N, ld, device='cuda', generator=gen) * 2.0 + 5.0
+    m0, s0, m1, s1 = _both(lib, _lib, torch, x, N, G)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    mg, sg = torch.zeros(G, device='cuda'), torch.zeros(G, device='cuda')
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    _lib.check(lib.agx_colstats_noalloc(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(x), ld, N, G, p(mg), p(sg)))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.equal(mg, m0) and torch.equal(sg, s0)
+    mg.zero_()
+    sg.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _lib.check(lib.agx_colstats_noalloc(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(x), ld, N, G, p(mg), p(sg)))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(mg, m0) and torch.equal(sg, s0)
     # beyond the static scratch: rejected before any launch, with a message that names the limit
     x = torch.zeros(2, 8, device='cuda')
     big = 65537
