@@ -70,6 +70,9 @@ class MlpDesc(C.Structure):
         ('emb', EmbedDesc),
         ('n_num', C.c_int32),
         ('n_flat', C.c_int64),
+        ('bn', C.c_int32), ('bn_eps', C.c_float), ('bn_momentum', C.c_float),
+        ('bn_gamma_off', C.c_int64 * AGX_MAX_LAYERS), ('bn_beta_off', C.c_int64 * AGX_MAX_LAYERS),
+        ('bn_mean_off', C.c_int64 * AGX_MAX_LAYERS), ('bn_var_off', C.c_int64 * AGX_MAX_LAYERS),
     ]
 
 
@@ -186,6 +189,8 @@ SIGNATURES = {
     'agx_gemm_sk_flag_words': (_i64, []),
     'agx_bn_fold': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _i32]),
     'agx_affine_act': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _f32]),
+    'agx_bn_backward': (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
+    'agx_bn_moving_update': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i32]),
     'agx_embed_concat_fwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32,
                                        _vp, _i32, _i32, _i32, _vp, _i32]),
     'agx_embed_bwd': (C.c_int, [_vp, C.POINTER(EmbedDesc), _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32]),

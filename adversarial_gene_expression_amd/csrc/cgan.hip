@@ -52,6 +52,13 @@ struct agx_cgan {
   float *gin0 = nullptr;                    // [S*Bm, ldg0] generator layer-1 input [z | num | emb]
   float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [S*Bm, ldgh]
   float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas      [Bm, ldgh]
+  // generator batch-norm (cfg.gen.bn; eager step functions only): pre-normalisation values of the training-mode
+  // forward, batch statistics per hidden layer, folded scale / shift, column-statistics scratch
+  float *gpre[AGX_MAX_LAYERS + 1] = {};     // [Bm, ldgh]
+  float *bn_mean[AGX_MAX_LAYERS + 1] = {}, *bn_std[AGX_MAX_LAYERS + 1] = {};
+  float *bn_scale = nullptr, *bn_shift = nullptr;
+  double *bn_ws = nullptr;
+  int64_t bn_ws_doubles = 0;
   float *F = nullptr;                       // [S*Bm, ldsx] fake rows of a whole captured iteration
   int ldgh[AGX_MAX_LAYERS + 1] = {};
   // staging for the captured iteration (agx_cgan_iter_*)
@@ -91,6 +98,12 @@ int validate_mlp(const agx_mlp_desc_t &m, const char *name, int want_in, int wan
                 want_in, m.n_num, e);
   AGX_CHECK_ARG(m.dims[m.n_layers] == want_out, "%s: output width %d != %d", name,
                 m.dims[m.n_layers], want_out);
+  if (m.bn) {
+    AGX_CHECK_ARG(m.bn_eps > 0.f && m.bn_momentum >= 0.f && m.bn_momentum <= 1.f, "%s: batch-norm eps / momentum", name);
+    for (int l = 0; l < m.n_layers - 1; ++l)
+      for (const int64_t off : {m.bn_gamma_off[l], m.bn_beta_off[l], m.bn_mean_off[l], m.bn_var_off[l]})
+        AGX_CHECK_ARG(off >= 0 && off % 4 == 0 && off + m.dims[l + 1] <= m.n_flat, "%s: batch-norm vector of layer %d outside the flat buffer", name, l);
+  }
   for (int l = 0; l < m.n_layers; ++l) {
     AGX_CHECK_ARG(m.dims[l + 1] > 0 && m.ldw[l] >= m.dims[l + 1], "%s: layer %d ldw", name, l);
     AGX_CHECK_ARG(m.w_off[l] >= 0 && m.w_off[l] % 4 == 0 && m.w_off[l] + (int64_t)m.dims[l] * m.ldw[l] <= m.n_flat,
@@ -137,6 +150,21 @@ void carve(agx_cgan *h, float *base) {
     h->ldgh[l] = r4(c.gen.dims[l]);
     h->gh[l] = cv.take((int64_t)S * Bm * h->ldgh[l]);
     h->gd[l] = cv.take((int64_t)Bm * h->ldgh[l]);
+  }
+  if (c.gen.bn) {
+    int64_t wsd = 0;
+    int maxh = 4;
+    for (int l = 1; l <= Lg; ++l) {
+      h->gpre[l] = cv.take((int64_t)Bm * h->ldgh[l]);
+      h->bn_mean[l] = cv.take(h->ldgh[l]);
+      h->bn_std[l] = cv.take(h->ldgh[l]);
+      wsd = std::max<int64_t>(wsd, agx_colstats_ws_doubles(Bm, c.gen.dims[l]));
+      maxh = std::max(maxh, h->ldgh[l]);
+    }
+    h->bn_scale = cv.take(maxh);
+    h->bn_shift = cv.take(maxh);
+    h->bn_ws_doubles = wsd;
+    h->bn_ws = reinterpret_cast<double *>(cv.take(2 * wsd));
   }
   h->ldsx = r4(c.x_dim);
   h->F = cv.take((int64_t)S * Bm * h->ldsx);
@@ -205,6 +233,7 @@ struct Gemm {  // GEMM call builder
   Gemm &act() { g.act = 1; return *this; }
   Gemm &mask(const float *m, int ld) { g.mask = m; g.ldmask = ld; return *this; }
   Gemm &rowscale(const float *r) { g.rowscale = r; return *this; }
+  Gemm &colaffine(const float *sc, const float *sh) { g.col_scale = sc; g.col_shift = sh; return *this; }
   Gemm &rowsq(float *q, int ld) { g.rowsq = q; g.rowsq_ld = ld; return *this; }
   Gemm &interp(int rows, const float *alpha) { g.interp_rows = rows; g.interp_alpha = alpha; return *this; }
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
@@ -233,12 +262,41 @@ int gen_input(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, c
 // batch: the rows of ONE training batch (R is a multiple of it in a captured iteration): the choice between the
 // two-layer kernel and the GEMM launches must not depend on how many batches are stacked, or the captured iteration
 // and the eager steps would round differently
-int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo, const agx::DualOut *dual = nullptr, int batch = 0) {
+// training (batch-norm generators only): batch statistics of the R rows (Keras training=True, tf_utils.py:244) and the
+// moving statistics updated; otherwise the moving statistics, folded into the Dense epilogue (training=False, :206)
+int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo, const agx::DualOut *dual = nullptr, int batch = 0,
+               bool training = false) {
   const agx_mlp_desc_t &m = h->cfg.gen;
   const float *in = h->gin0;
   int ldin = h->ldg0;
   int l0 = 0;
   static const bool gen_tail = getenv("AGX_NO_GEN_TAIL") == nullptr;
+  if (m.bn) {
+    for (int l = 0; l < m.n_layers - 1; ++l) {
+      float *o = h->gh[l + 1];
+      const int ldo_l = h->ldgh[l + 1], H = m.dims[l + 1];
+      const float *gamma = h->gp + m.bn_gamma_off[l], *beta = h->gp + m.bn_beta_off[l];
+      float *mm = h->gp + m.bn_mean_off[l], *mv = h->gp + m.bn_var_off[l];
+      Gemm g(h, in, ldin, 0, h->gp + m.w_off[l], m.ldw[l], 0, o, ldo_l, R, H, m.dims[l]);
+      g.bias(h->gp + m.b_off[l]).id(AGX_K_GEN_FWD_HID);
+      if (!training) {
+        AGX_TRY(agx_bn_fold(st, mm, mv, 0, gamma, beta, m.bn_eps, h->bn_scale, h->bn_shift, H));
+        AGX_TRY(g.colaffine(h->bn_scale, h->bn_shift).act().run(st));
+      } else {
+        AGX_CHECK_ARG(R <= h->Bm, "generator batch-norm: %d rows > max_batch %d", R, h->Bm);
+        AGX_TRY(g.run(st));
+        AGX_HIP(hipMemcpy2DAsync(h->gpre[l + 1], (size_t)ldo_l * 4, o, (size_t)ldo_l * 4, (size_t)H * 4, R,
+                                 hipMemcpyDeviceToDevice, st));
+        AGX_TRY(agx_colstats(st, o, ldo_l, R, H, h->bn_mean[l + 1], h->bn_std[l + 1], h->bn_ws, h->bn_ws_doubles));
+        AGX_TRY(agx_bn_fold(st, h->bn_mean[l + 1], h->bn_std[l + 1], 1, gamma, beta, m.bn_eps, h->bn_scale, h->bn_shift, H));
+        AGX_TRY(agx_affine_act(st, o, ldo_l, R, H, h->bn_scale, h->bn_shift, 1, h->cfg.slope));
+        AGX_TRY(agx_bn_moving_update(st, mm, mv, h->bn_mean[l + 1], h->bn_std[l + 1], m.bn_momentum, H));
+      }
+      in = o;
+      ldin = ldo_l;
+    }
+    l0 = m.n_layers - 1;
+  } else
   if (gen_tail && m.n_layers == 3 && m.dims[0] <= 128 && m.dims[1] <= 256 && m.dims[2] <= 256 && (batch > 0 ? batch : R) <= 64) {
     // small batches: both hidden layers in ONE launch (tail.hip mode 2; always 4 column groups, so that a row's
     // summation order does not depend on the number of rows)
@@ -537,6 +595,10 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
           gm.dims[l + 1]);
       g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
       AGX_TRY(g.run(st));
+      if (gm.bn)   // gd[l] = dL/d(normalised value) -> dL/d(Dense output), gamma / beta gradients of hidden layer l - 1
+        AGX_TRY(agx_bn_backward(st, h->gd[l], h->ldgh[l], h->gpre[l], h->ldgh[l], h->bn_mean[l], h->bn_std[l],
+                                h->gp + gm.bn_gamma_off[l - 1], gm.bn_eps, B, gm.dims[l], h->gg + gm.bn_gamma_off[l - 1],
+                                h->gg + gm.bn_beta_off[l - 1]));
     }
     if (fused && !(fo->rest_n > 0)) AGX_TRY(weight_grad());
     if (l > 0) {
@@ -592,6 +654,7 @@ extern "C" int agx_cgan_create(const agx_cgan_config_t *cfg, agx_cgan_t **out) {
   AGX_TRY(validate_mlp(cfg->gen, "generator", cfg->z_dim, cfg->x_dim));
   AGX_TRY(validate_mlp(cfg->disc, "critic", cfg->x_dim, 1));
   AGX_CHECK_ARG(cfg->disc.ldw[cfg->disc.n_layers - 1] == 1, "critic output kernel must have ldw == 1");
+  AGX_CHECK_ARG(!cfg->disc.bn, "agx_cgan_create: batch-norm in the critic is not supported (the gradient penalty is a per-sample quantity)");
   AGX_CHECK_ARG(cfg->gen.n_num == cfg->disc.n_num && cfg->gen.emb.n_cat == cfg->disc.emb.n_cat,
                 "generator and critic must share the covariate layout");
   agx_cgan *h = new (std::nothrow) agx_cgan();
@@ -686,7 +749,7 @@ extern "C" int agx_cgan_gen_grads(agx_cgan_t *h, void *stream, const agx_step_ar
   hipStream_t st = agx::as_stream(stream);
   const int B = a->B, G = h->G, ldx = h->ldx;
   AGX_TRY(gen_input(h, st, a->z, a->cat, a->num, B, B));
-  AGX_TRY(gen_layers(h, st, B, h->X, ldx));                                                    // :244
+  AGX_TRY(gen_layers(h, st, B, h->X, ldx, nullptr, 0, true));                                  // :244 (training=True)
   if (a->aug_mask) AGX_TRY(agx_aug_add(st, h->X, ldx, a->aug_mask, a->aug_noise_fake, G, 0, B, G));  // :247
   AGX_TRY(disc_cov_columns(h, st, a->cat, a->num, B, B));
   return gen_core(h, st, a->cat, B, a->B_global, 0, a->losses);
@@ -926,6 +989,7 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   AGX_CHECK_ARG(!a->aug_mask_disc || (a->aug_noise_fake && a->aug_noise_real), "agx_cgan_iter_capture: critic aug noise missing");
   AGX_CHECK_ARG(!a->aug_mask_gen || a->aug_noise_gen, "agx_cgan_iter_capture: generator aug noise missing");
   AGX_CHECK_ARG(stream != nullptr, "agx_cgan_iter_capture: capture needs a non-default stream");
+  AGX_CHECK_ARG(!h->cfg.gen.bn, "agx_cgan_iter_capture: batch-norm generators run through the eager step functions only");
   if (agx_prof_enabled()) {
     agx::set_error("agx_cgan_iter_capture: event brackets cannot be captured; call agx_prof_enable(-2) first");
     return AGX_E_STATE;
@@ -1045,6 +1109,7 @@ extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_a
   AGX_CHECK_ARG(a->B > 0 && a->B <= h->Bm && ldx >= h->G, "agx_cgan_iter_eager: batch %d outside (0, %d] or ldx < x_dim", a->B, h->Bm);
   AGX_CHECK_ARG(a->nb_critic >= 0 && a->nb_critic < h->S, "agx_cgan_iter_eager: nb_critic %d needs max_steps > %d", a->nb_critic, a->nb_critic);
   AGX_CHECK_ARG(!a->split, "agx_cgan_iter_eager: one-GPU form only");
+  AGX_CHECK_ARG(!h->cfg.gen.bn, "agx_cgan_iter_eager: batch-norm generators run through the eager step functions only");
   AGX_CHECK_ARG(a->opt_kind == 1 ? (a->disc_m && a->disc_v && a->gen_m && a->gen_v && a->adam_lr_t_host)
                                  : (a->opt_kind == 0 && a->disc_rms && a->gen_rms),
                 "agx_cgan_iter_eager: optimizer slots (and adam_lr_t_host for Adam) required");

@@ -1411,6 +1411,80 @@ __global__ void __launch_bounds__(256) affine_act_kernel(float *__restrict__ y, 
 }
 }  // namespace
 
+namespace {
+// one workgroup per 32 columns: 32 column lanes x 8 row lanes; the 8 partial sums of a column meet in LDS in a fixed order
+__global__ void __launch_bounds__(256) bn_backward_kernel(float *__restrict__ dz, int lddz, const float *__restrict__ x, int ldx,
+                                                          const float *__restrict__ mean, const float *__restrict__ sd,
+                                                          const float *__restrict__ gamma, float eps, int M, int N,
+                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool ok = c < N;
+  const float mu = ok ? mean[c] : 0.f, s0 = ok ? sd[c] : 1.f;
+  const float inv = 1.f / sqrtf(s0 * s0 + eps);
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int r = rl; r < M; r += 8) {
+      const float d = dz[(size_t)r * lddz + c];
+      const float xh = (x[(size_t)r * ldx + c] - mu) * inv;
+      s1 += d;
+      s2 += d * xh;
+    }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  s1 = 0.f;
+  s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    s1 += red[0][k][cl];
+    s2 += red[1][k][cl];
+  }
+  if (!ok) return;
+  if (rl == 0) {
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+  }
+  const float g = (gamma ? gamma[c] : 1.f) * inv, m1 = s1 / (float)M, m2 = s2 / (float)M;
+  for (int r = rl; r < M; r += 8) {
+    const float xh = (x[(size_t)r * ldx + c] - mu) * inv;
+    float *p = dz + (size_t)r * lddz + c;
+    *p = g * (*p - m1 - xh * m2);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_moving_kernel(float *__restrict__ mm, float *__restrict__ mv,
+                                                        const float *__restrict__ mean, const float *__restrict__ sd,
+                                                        float momentum, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  mm[n] = momentum * mm[n] + (1.f - momentum) * mean[n];
+  mv[n] = momentum * mv[n] + (1.f - momentum) * (sd[n] * sd[n]);
+}
+}  // namespace
+
+extern "C" int agx_bn_backward(void *stream, float *dz, int32_t lddz, const float *x, int32_t ldx, const float *mean,
+                               const float *std, const float *gamma, float eps, int32_t M, int32_t N, float *dgamma,
+                               float *dbeta) {
+  AGX_CHECK_ARG(dz && x && mean && std && dgamma && dbeta && M > 0 && N > 0 && lddz >= N && ldx >= N && eps >= 0.f,
+                "agx_bn_backward: bad argument");
+  hipLaunchKernelGGL(bn_backward_kernel, dim3(agx::cdiv(N, 32)), dim3(256), 0, agx::as_stream(stream), dz, lddz, x, ldx, mean,
+                     std, gamma, eps, M, N, dgamma, dbeta);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+extern "C" int agx_bn_moving_update(void *stream, float *moving_mean, float *moving_var, const float *mean, const float *std,
+                                    float momentum, int32_t N) {
+  AGX_CHECK_ARG(moving_mean && moving_var && mean && std && N > 0 && momentum >= 0.f && momentum <= 1.f,
+                "agx_bn_moving_update: bad argument");
+  hipLaunchKernelGGL(bn_moving_kernel, dim3(agx::cdiv(N, 256)), dim3(256), 0, agx::as_stream(stream), moving_mean, moving_var,
+                     mean, std, momentum, N);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
 extern "C" int agx_bn_fold(void *stream, const float *mean, const float *var_or_std, int32_t is_std,
                            const float *gamma, const float *beta, float eps, float *scale, float *shift, int32_t N) {
   AGX_CHECK_ARG(mean && var_or_std && scale && shift && N > 0 && eps >= 0.f, "agx_bn_fold: bad argument");

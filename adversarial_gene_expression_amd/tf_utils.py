@@ -99,9 +99,21 @@ class _Net:
 
     kind = None
 
-    def __init__(self, x_dim, vocab_sizes, nb_numeric, h_dims, z_dim, slope=0.0, weights=None, seed=None):
+    def __init__(self, x_dim, vocab_sizes, nb_numeric, h_dims, z_dim, slope=0.0, weights=None, seed=None,
+                 batch_norm=False, bn_epsilon=1e-3, bn_momentum=0.99):
         if h_dims is None:
             h_dims = [256, 256]
+        # optional BatchNormalization after every hidden Dense, before the activation (BASELINE.json north_star; the
+        # reference has none, tf_utils.py:85-88, so this is OFF on every parity path).  Generator only - the critic's
+        # gradient penalty is a per-sample quantity that batch statistics would couple (tf_utils.py:154-171) - and
+        # the eager step functions only (train() falls back to them).  Keras semantics: train_gen normalises with
+        # batch statistics and updates the moving ones (training=True, :244), train_disc and predict use the moving
+        # statistics (training=False, :206, :372-375).
+        self.batch_norm = bool(batch_norm)
+        self.bn_epsilon, self.bn_momentum = float(bn_epsilon), float(bn_momentum)
+        if self.batch_norm and self.kind != 'gen':
+            raise NotImplementedError('batch_norm is available for the generator only: the WGAN-GP critic is penalised per '
+                                      'sample (tf_utils.py:154-171), batch statistics would couple the samples')
         if len(h_dims) < 1 or len(h_dims) + 1 > _lib.AGX_MAX_LAYERS:
             raise ValueError('h_dims must have between 1 and %d entries' % (_lib.AGX_MAX_LAYERS - 1))
         if len(vocab_sizes) > _lib.AGX_MAX_CAT:
@@ -139,6 +151,7 @@ class _Net:
             self.emb_off.append(off)
             off = a64(off + v * e)
         self.ldw, self.w_off, self.b_off = [], [], []
+        self.bn_off = []      # per hidden layer: flat offsets of (gamma, beta, moving_mean, moving_variance)
         for l in range(len(self.dims) - 1):
             n = self.dims[l + 1]
             ld = 1 if n == 1 else _dev.r4(n)
@@ -147,6 +160,12 @@ class _Net:
             off = a64(off + self.dims[l] * ld)
             self.b_off.append(off)
             off = a64(off + n)
+            if self.batch_norm and l < len(self.dims) - 2:
+                four = []
+                for _ in range(4):
+                    four.append(off)
+                    off = a64(off + n)
+                self.bn_off.append(tuple(four))
         self.n_flat = off
         d = _lib.MlpDesc()
         d.n_layers = len(self.dims) - 1
@@ -159,6 +178,10 @@ class _Net:
             d.emb.vocab[i], d.emb.edim[i], d.emb.table_off[i] = self.vocab_sizes[i], self.emb_dims[i], self.emb_off[i]
         d.n_num = self.nb_numeric
         d.n_flat = self.n_flat
+        d.bn = int(self.batch_norm)
+        d.bn_eps, d.bn_momentum = self.bn_epsilon, self.bn_momentum
+        for l, four in enumerate(self.bn_off):
+            d.bn_gamma_off[l], d.bn_beta_off[l], d.bn_mean_off[l], d.bn_var_off[l] = four
         self.desc = d
 
     def _initial_weights(self, seed):
@@ -170,22 +193,33 @@ class _Net:
             lim = math.sqrt(6.0 / (self.dims[l] + self.dims[l + 1]))
             ws.append(rs.uniform(-lim, lim, size=(self.dims[l], self.dims[l + 1])).astype(np.float32))
             ws.append(np.zeros(self.dims[l + 1], np.float32))
+            if self.batch_norm and l < len(self.dims) - 2:     # Keras BatchNormalization: gamma 1, beta 0, moving 0 / 1
+                n = self.dims[l + 1]
+                ws += [np.ones(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32), np.ones(n, np.float32)]
         return ws
 
     def _segments(self):
-        """(flat offset, rows, cols, ld) per variable in Keras order."""
+        """(flat offset, rows, cols, ld) per variable in Keras `get_weights()` order (a batch-norm layer contributes
+        gamma, beta, moving_mean, moving_variance behind its Dense)."""
         segs = [(o, v, e, e) for o, v, e in zip(self.emb_off, self.vocab_sizes, self.emb_dims)]
+        self._vector_seg, self._frozen_seg = set(), set()
         for l in range(len(self.dims) - 1):
             segs.append((self.w_off[l], self.dims[l], self.dims[l + 1], self.ldw[l]))
+            self._vector_seg.add(len(segs))
             segs.append((self.b_off[l], 1, self.dims[l + 1], self.dims[l + 1]))
+            if self.batch_norm and l < len(self.bn_off):
+                for q, o in enumerate(self.bn_off[l]):
+                    self._vector_seg.add(len(segs))
+                    if q >= 2:
+                        self._frozen_seg.add(len(segs))      # moving statistics: not trainable
+                    segs.append((o, 1, self.dims[l + 1], self.dims[l + 1]))
         return segs
 
     def _unflatten(self, flat_host):
         out = []
         for k, (o, r, c, ld) in enumerate(self._segments()):
             a = flat_host[o:o + r * ld].reshape(r, ld)[:, :c]
-            is_bias = k >= len(self.vocab_sizes) and (k - len(self.vocab_sizes)) % 2 == 1
-            out.append(a.reshape(-1).copy() if is_bias else a.copy())
+            out.append(a.reshape(-1).copy() if k in self._vector_seg else a.copy())
         return out
 
     def _flatten(self, arrays):
@@ -210,7 +244,9 @@ class _Net:
 
     @property
     def trainable_variables(self):
-        return [DeviceArray(self.params[o:o + r * ld].view(r, ld)[:, :c]) for o, r, c, ld in self._segments()]
+        segs = self._segments()
+        return [DeviceArray(self.params[o:o + r * ld].view(r, ld)[:, :c]) for k, (o, r, c, ld) in enumerate(segs)
+                if k not in self._frozen_seg]
 
     def count_params(self):
         return sum(r * c for _, r, c, _ in self._segments())
@@ -220,6 +256,8 @@ class _Net:
         names = ['embedding_%d' % i for i in range(len(self.vocab_sizes))]
         for l in range(len(self.dims) - 1):
             names += ['dense_%d/kernel' % l, 'dense_%d/bias' % l]
+            if self.batch_norm and l < len(self.bn_off):
+                names += ['batch_normalization_%d/%s' % (l, q) for q in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
         for n, (_, r, c, _) in zip(names, self._segments()):
             print('  %-22s %-16s %d' % (n, (r, c) if r > 1 or 'kernel' in n or 'emb' in n else (c,), r * c))
         print('Total params: {:,}'.format(self.count_params()))
@@ -231,6 +269,8 @@ class _Net:
             os.makedirs(d, exist_ok=True)
         cfg = dict(kind=self.kind, x_dim=self.x_dim, z_dim=self.z_dim, vocab_sizes=self.vocab_sizes,
                    nb_numeric=self.nb_numeric, h_dims=self.h_dims, slope=self.slope)
+        if self.batch_norm:
+            cfg.update(batch_norm=True, bn_epsilon=self.bn_epsilon, bn_momentum=self.bn_momentum)
         np.savez(path, __config__=np.array(repr(cfg)), **{'w%03d' % i: w for i, w in enumerate(self.get_weights())})
 
     # -- forward (op-level ABI) ---------------------------------------------
@@ -254,7 +294,12 @@ class _Net:
             n, k = self.dims[l + 1], self.dims[l]
             w = self.params[self.w_off[l]:self.w_off[l] + k * self.ldw[l]].view(k, self.ldw[l])
             b = self.params[self.b_off[l]:self.b_off[l] + n]
-            h = ops.gemm(h, w, rows, n, k, bias=b, act=1 if l < nl - 1 else 0, slope=self.slope)
+            if self.batch_norm and l < nl - 1:       # moving statistics (training=False)
+                ga, be, mm, mv = (self.params[o:o + n] for o in self.bn_off[l])
+                h = ops.dense_bn(h, w, b, rows, n, k, gamma=ga, beta=be, eps=self.bn_epsilon, slope=self.slope,
+                                 running=(mm, mv))[0]
+            else:
+                h = ops.gemm(h, w, rows, n, k, bias=b, act=1 if l < nl - 1 else 0, slope=self.slope)
             acts.append(h)
         out = h[:, :self.dims[-1]]
         return (out, acts) if keep else out
@@ -300,7 +345,7 @@ def load_model(path):
     cfg = _check_model_config(cfg)
     cls = Generator if cfg['kind'] == 'gen' else Critic
     return cls(cfg['x_dim'], cfg['vocab_sizes'], cfg['nb_numeric'], cfg['h_dims'], cfg['z_dim'],
-               slope=cfg['slope'], weights=ws)
+               slope=cfg['slope'], weights=ws, **{k: cfg[k] for k in ('batch_norm', 'bn_epsilon', 'bn_momentum') if k in cfg})
 
 
 def _check_model_config(cfg):
@@ -315,8 +360,13 @@ def _check_model_config(cfg):
           and isinstance(cfg.get('slope', 0.0), (int, float)))
     if not ok:
         raise ValueError('model file: malformed __config__ %r' % (cfg,))
+    bn = {}
+    if cfg.get('batch_norm', False):
+        if cfg['batch_norm'] is not True or not all(isinstance(cfg.get(k), float) and cfg[k] > 0 for k in ('bn_epsilon', 'bn_momentum')):
+            raise ValueError('model file: malformed batch-norm entries in __config__ %r' % (cfg,))
+        bn = dict(batch_norm=True, bn_epsilon=cfg['bn_epsilon'], bn_momentum=cfg['bn_momentum'])
     return dict(kind=cfg['kind'], x_dim=cfg['x_dim'], z_dim=cfg['z_dim'], nb_numeric=cfg['nb_numeric'],
-                vocab_sizes=list(cfg['vocab_sizes']), h_dims=list(cfg['h_dims']), slope=float(cfg.get('slope', 0.0)))
+                vocab_sizes=list(cfg['vocab_sizes']), h_dims=list(cfg['h_dims']), slope=float(cfg.get('slope', 0.0)), **bn)
 
 
 # ---------------------------------------------------------------------------
@@ -877,6 +927,9 @@ def train_disc(x, z, cc, nc, gen, disc, disc_opt, grad_penalty_weight=10, p_aug=
         raise ValueError('x must be [%d, %d], got %s' % (B, gen.x_dim, tuple(x.shape)))
     pair = _pair(gen, disc, B)
     world, _ = _world()
+    if world > 1 and gen.batch_norm:
+        raise NotImplementedError('batch-norm generators are not available under data parallelism (batch statistics '
+                                  'would need their own exchange)')
     Bg = int(batch_global) if batch_global else B * world
     alpha = random_uniform((B,)) if alpha is None else _dev.to_dev(alpha).reshape(-1)
     losses = disc.grads.data_ptr() + 4 * disc.n_flat
@@ -913,6 +966,8 @@ def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None,
     nc = _dev.to_dev(nc)
     pair = _pair(gen, disc, B)
     world, _ = _world()
+    if world > 1 and gen.batch_norm:
+        raise NotImplementedError('batch-norm generators are not available under data parallelism')
     Bg = int(batch_global) if batch_global else B * world
     losses = gen.grads.data_ptr() + 4 * gen.n_flat
     a = _step_args(pair, z, cc, nc, B, Bg, losses)
@@ -933,7 +988,9 @@ def train_gen(z, cc, nc, gen, disc, gen_opt, p_aug=0, norm_scale=1, *, aug=None,
     return DeviceArray(gen.grads[gen.n_flat:gen.n_flat + 1].clone())
 
 
-def _graph_ok(gen_opt, disc_opt, world=1):
+def _graph_ok(gen_opt, disc_opt, world=1, gen=None):
+    if gen is not None and getattr(gen, 'batch_norm', False):
+        return False      # batch-norm generators: eager step functions (training-mode forward in train_gen only)
     if type(gen_opt) is RMSprop and type(disc_opt) is RMSprop:
         return gen_opt.rho == disc_opt.rho and gen_opt.epsilon == disc_opt.epsilon
     if type(gen_opt) is Adam and type(disc_opt) is Adam:
@@ -976,9 +1033,9 @@ def train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic=5, grad_p
     nc = _dev.to_dev(nc)
     B = x.shape[0]
     world, _ = _world()
-    if not _graph_ok(gen_opt, disc_opt):
+    if not _graph_ok(gen_opt, disc_opt, gen=gen):
         raise ValueError('train_iteration needs the same optimizer class (RMSprop or Adam) with equal decay rates / '
-                         'epsilon on both networks')
+                         'epsilon on both networks, and a generator without batch-norm')
     Bg = int(batch_global) if batch_global else B * world
     if world == 1 and Bg != B:
         raise ValueError('batch_global differs from the local batch on a single GPU')
@@ -1075,7 +1132,7 @@ def train(dataset, cat_covs, num_covs, z_dim, epochs, batch_size, gen, disc, sco
             if hi_r <= lo_r:
                 raise ValueError('global batch of %d rows cannot be split over %d ranks' % (bg, world))
             x, cc, nc = data[lo_r:hi_r], ccs[lo_r:hi_r], ncs[lo_r:hi_r]
-            if use_graph and noise_fn is None and nb_critic > 0 and _graph_ok(gen_opt, disc_opt):
+            if use_graph and noise_fn is None and nb_critic > 0 and _graph_ok(gen_opt, disc_opt, gen=gen):
                 d_l, g_l = train_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, 10, p_aug, norm_scale,
                                            batch_global=bg, row_lo=lo_r - i)
                 dl.append(d_l)

@@ -141,6 +141,19 @@ int agx_bn_fold(void *stream, const float *mean, const float *var_or_std, int32_
 /* y[m,n] = act(y[m,n]*scale[n] + shift[n]) in place; act: leaky-ReLU with `slope` (0 = ReLU), act = 0: none */
 int agx_affine_act(void *stream, float *y, int32_t ldy, int32_t M, int32_t N, const float *scale,
                    const float *shift, int32_t act, float slope);
+/* Backward of y = gamma * (x - mean) / sqrt(std^2 + eps) + beta over the M batch rows (batch statistics:
+ * mean / std are functions of x), in place: on entry dz = dL/dy [M, N] (ld lddz), on return dL/dx:
+ *   xhat = (x - mean) / sqrt(std^2 + eps);  dbeta = sum_m dz;  dgamma = sum_m dz * xhat;
+ *   dx = gamma / sqrt(std^2 + eps) * (dz - dbeta / M - xhat * dgamma / M)
+ * x: the layer's pre-normalisation values [M, N] (ld ldx); mean / std: what agx_colstats returned for them.
+ * Column sums in a fixed order (deterministic).  No reference counterpart (tf_utils.py:85-88 has no BN). */
+int agx_bn_backward(void *stream, float *dz, int32_t lddz, const float *x, int32_t ldx, const float *mean,
+                    const float *std, const float *gamma, float eps, int32_t M, int32_t N, float *dgamma,
+                    float *dbeta);
+/* Keras moving statistics: mm = momentum * mm + (1 - momentum) * mean, mv = momentum * mv + (1 - momentum) * std^2
+ * (biased batch variance: the non-fused path Keras takes for 2-D inputs) */
+int agx_bn_moving_update(void *stream, float *moving_mean, float *moving_var, const float *mean, const float *std,
+                         float momentum, int32_t N);
 
 /* ---- embeddings: tf_utils.py:64-76, 120-131 ---------------------------- */
 typedef struct agx_embed {
@@ -365,6 +378,16 @@ typedef struct agx_mlp_desc {
   agx_embed_t emb;                  /* table_off are flat offsets too           */
   int32_t n_num;
   int64_t n_flat;                   /* flat length incl. padding                */
+  /* optional BatchNormalization after every hidden Dense, before the activation (north_star; the reference has   */
+  /* none, tf_utils.py:85-88: bn = 0 on every parity path).  GENERATOR only (the critic's gradient penalty is a     */
+  /* per-sample quantity: batch statistics would couple the samples) and eager step functions only.  Per hidden   */
+  /* layer l four vectors of dims[l+1] floats in the flat buffer: gamma, beta (trained) and the moving mean /      */
+  /* variance (their gradient entries stay 0, so the optimizer leaves them alone; updated by the training-mode    */
+  /* forward).  Keras semantics: train_gen runs the generator with training=True (batch statistics, :244),        */
+  /* train_disc and predict with training=False (moving statistics, :206, :372-375).                              */
+  int32_t bn;
+  float bn_eps, bn_momentum;        /* Keras defaults 1e-3, 0.99 */
+  int64_t bn_gamma_off[AGX_MAX_LAYERS], bn_beta_off[AGX_MAX_LAYERS], bn_mean_off[AGX_MAX_LAYERS], bn_var_off[AGX_MAX_LAYERS];
 } agx_mlp_desc_t;
 
 typedef struct agx_cgan_config {
