@@ -1699,6 +1699,10 @@ Plan make_plan(int M, int N, int K, int force_cfg, int force_splitk, int64_t ws_
   //  or 512 makes 228 / 456 tiles = one round - measured 169.8 against 173.6 us on the 512-row dW_1 (one workgroup per
   //  CU has nothing to overlap with), 63.0 against 58.8 us on the input gradient, 347 against 327 us on the generator
   //  output layer; 230-256 registers with spills in four layouts: profiles/r02_tile160.txt)
+  // (a 192x64 tile of 4 waves x three blocks - every row of the generator's stacked output layer 192 x 18154 x 256 in ONE
+  //  tile, W_out streamed once, 284 workgroups - measured 35.9 against 29.8 us for the 64x64 tiling, which every other
+  //  configuration here loses to as well (31.9 .. 60.9 us): with 8 K-tiles a workgroup is load-latency-bound and four
+  //  resident 64x64 workgroups per CU overlap that where one large one cannot; profiles/r03_gen_out_tile_sweep.txt, cfg40 = that tile)
   if (cfg >= 20) {
     pl.bm = pl.bn = 128;
   } else if (cfg >= 8) {
