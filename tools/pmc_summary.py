@@ -3,6 +3,7 @@
 
     python tools/pmc_summary.py mfma <csv>            MFMA pipe utilisation per kernel
     python tools/pmc_summary.py traffic <fetch_csv> <write_csv>   HBM-side bytes per launch per kernel
+    python tools/pmc_summary.py raw <csv>             every collected counter per launch per kernel
 
 mfma: SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's SIMD matrix pipes (cycles); the kernel's
 wall cycles are GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs, MI355X_MICROARCH.md 'DVFS give-back'),
@@ -50,6 +51,12 @@ def main():
         print('%-80s %6s %10s %9s %9s %8s' % ('kernel', 'calls', 'total_us', 'mfma_util', 'sq_busy', 'GHz'))
         for d, k, n, u, sb, ghz in sorted(rows, reverse=True)[:24]:
             print('%-80s %6d %10.1f %9.3f %9.3f %8.2f' % (k, n, d / 1e3, u, sb, ghz))
+    elif mode == 'raw':
+        per, cnt, dur = load(sys.argv[2])
+        names = sorted({c for v in per.values() for c in v})
+        print('%-80s %6s %10s ' % ('kernel', 'calls', 'total_us') + ' '.join('%24s' % n for n in names))
+        for d, k in sorted(((dur[k], k) for k in per), reverse=True)[:24]:
+            print('%-80s %6d %10.1f ' % (k, cnt[k], d / 1e3) + ' '.join('%24.0f' % (per[k].get(n, 0.0) / max(cnt[k], 1)) for n in names))
     else:
         pf, cf, _ = load(sys.argv[2])
         pw, cw, _ = load(sys.argv[3])
