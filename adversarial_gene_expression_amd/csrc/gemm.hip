@@ -1770,6 +1770,10 @@ int gemm_prepare_device() {
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, false, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 16, true, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 16, true, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 16, true>()));
+  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 16, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true, true>()));
   // stream-K form of the plain 128x128 TN product
@@ -1934,6 +1938,7 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   //  NOT counted: SURVEY 8(d) prices the product and its optimizer traffic only; bench.py lists them apart)
   p.opt_tiles = pl.tiles;
   int rc;
+  static const bool bk16 = getenv("AGX_OPT_BK16") != nullptr;
   if (pl.sk_wgs) {
     p.sk_part = g->ws; p.sk_flags = g->sk_flags; p.sk_wgs = pl.sk_wgs; p.sk_nxcd = 8;
     p.opt_tiles = pl.sk_wgs;
@@ -1941,6 +1946,12 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   } else if (opt && pl.cfg == 0)
     rc = vec ? launch<128, 128, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
              : launch<128, 128, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
+  else if (opt && bk16 && g->K <= 512)
+    rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 16, true, true>(st, p, pl.tiles)
+             : launch<64, 64, 2, 2, true, false, false, false, 16, true, true>(st, p, pl.tiles);
+  else if (opt && bk16)
+    rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 16, true>(st, p, pl.tiles)
+             : launch<64, 64, 2, 2, true, false, false, false, 16, true>(st, p, pl.tiles);
   else if (opt && g->K <= 512)   // short K (batch < 128): the epilogue's instruction stream is on the critical path
     rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 32, true, true>(st, p, pl.tiles)
              : launch<64, 64, 2, 2, true, false, false, false, 32, true, true>(st, p, pl.tiles);

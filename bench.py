@@ -166,17 +166,40 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True)
         # The library-driven overlapped exchange (agx_cgan_dp_iteration over libagx's own RCCL communicator) is the
         # default under RCCL.  It has only ever run with ONE rank on the builder's one-GPU boxes: if any rank fails to
         # bring it up, ALL ranks fall back together to the c10d-driven exchange (tf_utils._dp_update).
-        ok = 1.0
-        try:
-            iteration(next_i())
+        # Brought up in stages, each closed by a MIN all-reduce over c10d, so that no rank enters a collective of
+        # the library's communicator that another rank never reaches: (1) the communicator itself, (2) one small
+        # sum on it, checked, (3) the first overlapped iteration.
+        from adversarial_gene_expression_amd import _dev
+
+        def all_ok(stage, fn):
+            ok = 1.0
+            try:
+                fn()
+                torch.cuda.synchronize()
+            except Exception as e:          # noqa: BLE001 - anything: the fall-back must be collective
+                print('[bench rank %d] overlapped exchange: %s failed (%r)' % (rank, stage, e), file=sys.stderr, flush=True)
+                ok = 0.0
+            t = torch.tensor([ok], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return float(t.item()) >= 1.0
+
+        def probe_sum():
+            one = torch.ones(256, device='cuda')
+            _dev.allreduce_sum(one)
             torch.cuda.synchronize()
-        except Exception as e:          # noqa: BLE001 - anything: the fall-back must be collective
-            print('[bench rank %d] overlapped exchange failed (%r): falling back' % (rank, e), file=sys.stderr, flush=True)
-            ok = 0.0
-        t = torch.tensor([ok], device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if float(t.item()) < 1.0:
+            if float(one[0].item()) != float(world) or float(one[-1].item()) != float(world):
+                raise RuntimeError('sum of ones over %d ranks = %r' % (world, float(one[0].item())))
+
+        def need_comm():
+            if _dev.native_comm() is None:
+                raise RuntimeError('no native communicator')
+
+        up = all_ok('communicator', need_comm) and all_ok('probe all-reduce', probe_sum) \
+            and all_ok('first iteration', lambda: iteration(next_i()))
+        if not up:
+            print('[bench rank %d] falling back to the c10d-driven exchange' % rank, file=sys.stderr, flush=True)
             os.environ['AGX_DP_OVERLAP'] = '0'
+            os.environ['AGX_NATIVE_COMM'] = '0'
     iteration(next_i())                        # first call: workspace, graph capture
     sync()
     nprobe = 3
