@@ -1757,7 +1757,7 @@ namespace agx {
 // agx_init, so that no attribute call happens inside a stream capture).
 int gemm_prepare_device() {
   AGX_TRY((prepare_cfg<128, 128, 2, 2>()));
-  AGX_TRY((prepare_cfg<64, 64, 2, 2>()));
+  AGX_TRY((prepare_cfg<64, 64, 2, 2, 16>()));
   AGX_TRY((prepare_cfg<32, 128, 1, 4>()));
   AGX_TRY((prepare_cfg<128, 128, 2, 4>()));
   AGX_TRY((prepare_cfg<128, 128, 2, 2, 16>()));
@@ -1768,12 +1768,8 @@ int gemm_prepare_device() {
   // weight-gradient products with the optimizer in the epilogue (TN layout)
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, true, false, 32, true>()));
   AGX_TRY((prepare_one<128, 128, 2, 2, true, false, false, false, 32, true>()));
-  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true>()));
-  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 16, true, true>()));
-  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 16, true, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 16, true>()));
-  AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 16, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, true, false, 32, true, true>()));
   AGX_TRY((prepare_one<64, 64, 2, 2, true, false, false, false, 32, true, true>()));
   // stream-K form of the plain 128x128 TN product
@@ -1938,7 +1934,6 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   //  NOT counted: SURVEY 8(d) prices the product and its optimizer traffic only; bench.py lists them apart)
   p.opt_tiles = pl.tiles;
   int rc;
-  static const bool bk16 = getenv("AGX_OPT_BK16") != nullptr;
   if (pl.sk_wgs) {
     p.sk_part = g->ws; p.sk_flags = g->sk_flags; p.sk_wgs = pl.sk_wgs; p.sk_nxcd = 8;
     p.opt_tiles = pl.sk_wgs;
@@ -1946,22 +1941,23 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
   } else if (opt && pl.cfg == 0)
     rc = vec ? launch<128, 128, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
              : launch<128, 128, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
-  else if (opt && bk16 && g->K <= 512)
-    rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 16, true, true>(st, p, pl.tiles)
-             : launch<64, 64, 2, 2, true, false, false, false, 16, true, true>(st, p, pl.tiles);
-  else if (opt && bk16)
-    rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 16, true>(st, p, pl.tiles)
-             : launch<64, 64, 2, 2, true, false, false, false, 16, true>(st, p, pl.tiles);
   else if (opt && g->K <= 512)   // short K (batch < 128): the epilogue's instruction stream is on the critical path
     rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 32, true, true>(st, p, pl.tiles)
              : launch<64, 64, 2, 2, true, false, false, false, 32, true, true>(st, p, pl.tiles);
+  else if (opt && vec)
+    // long K (the 512-row dW_1): K-tiles of 16; same k order, same bits: 2.679 against 2.703 ms per 512-row
+    // iteration (112 registers: 4 workgroups per CU instead of 3; profiles/r03_fused_dw1_residency.txt; at K <= 512
+    // it measured 0.5 % slower)
+    rc = launch<64, 64, 2, 2, true, false, true, false, 16, true>(st, p, pl.tiles);
   else if (opt)
-    rc = vec ? launch<64, 64, 2, 2, true, false, true, false, 32, true>(st, p, pl.tiles)
-             : launch<64, 64, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
+    rc = launch<64, 64, 2, 2, true, false, false, false, 32, true>(st, p, pl.tiles);
   else if (pl.cfg == 0)
     rc = launch_layout<128, 128, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 1)
-    rc = launch_layout<64, 64, 2, 2>(st, p, pl.tiles, g->ta, g->tb, vec);
+    // K-tiles of 16 (16 KB of LDS per workgroup): same k order, same bits as K-tiles of 32, and 1-2.5 % faster on every
+    // 64x64-tiled product of the iteration (profiles/r03_fused_dw1_residency.txt).  Not a residency effect: these
+    // kernels hold 144 registers (128 + 16 accumulators), i.e. 3 workgroups per CU either way.
+    rc = launch_layout<64, 64, 2, 2, 16>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 2)
     rc = launch_layout<32, 128, 1, 4>(st, p, pl.tiles, g->ta, g->tb, vec);
   else if (pl.cfg == 5)
@@ -1999,7 +1995,7 @@ int agx::gemm_run(void *stream, const agx_gemm_t *g, const agx::FusedOpt *fo, in
 }
 
 // measurement only: resident workgroups per CU the runtime computes for the main tile configurations
-// which: 0 = 64x64 NT, 1 = 64x64 TN fused optimizer, 2 = 128x128 NN 8-wave, 3 = 128x128 SYRK, 4 = 64x64 NN
+// which: 0 = 64x64 NT, 1 = 64x64 TN fused optimizer (long K: K-tiles of 16), 2 = 128x128 NN 8-wave, 3 = 128x128 SYRK, 4 = 64x64 NN
 extern "C" int agx_prof_occupancy(int32_t which, int32_t *blocks_per_cu, int32_t *lds_bytes) {
   AGX_CHECK_ARG(blocks_per_cu && lds_bytes, "agx_prof_occupancy: null argument");
   int nb = 0;
@@ -2007,11 +2003,11 @@ extern "C" int agx_prof_occupancy(int32_t which, int32_t *blocks_per_cu, int32_t
   hipError_t e = hipErrorInvalidValue;
   constexpr size_t l64 = 2 * (size_t)(64 * 32 + 64 * 32) * sizeof(float), l128 = 2 * (size_t)(128 * 32 + 128 * 32) * sizeof(float);
   switch (which) {
-    case 0: lds = l64; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, false, true, true, false, 32, 0, false, false>, 256, lds); break;
-    case 1: lds = l64; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, true, false, true, false, 32, 0, true, false>, 256, lds); break;
+    case 0: lds = l64 / 2; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, false, true, true, false, 16, 0, false, false>, 256, lds); break;
+    case 1: lds = l64 / 2; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, true, false, true, false, 16, 0, true, false>, 256, lds); break;
     case 2: lds = l128; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<128, 128, 2, 4, false, false, true, false, 32, 0, false, false>, 512, lds); break;
     case 3: lds = l128; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<128, 128, 2, 2, true, false, true, true, 32, 0, false, false>, 256, lds); break;
-    case 4: lds = l64; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, false, false, true, false, 32, 0, false, false>, 256, lds); break;
+    case 4: lds = l64 / 2; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<64, 64, 2, 2, false, false, true, false, 16, 0, false, false>, 256, lds); break;
     case 5: lds = l128; e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<128, 128, 2, 2, false, false, true, false, 32, 0, false, false>, 256, lds); break;
     default: AGX_CHECK_ARG(false, "agx_prof_occupancy: which = %d", which);
   }
