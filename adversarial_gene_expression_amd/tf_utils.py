@@ -719,10 +719,21 @@ def _exchange_layout(net, world, rank):
     return total, shard, rank * shard
 
 
-def _dp_chunks():
-    """Pieces of the data-parallel exchange (AGX_DP_CHUNKS; 0 = one piece: the flat one-shard-per-rank layout).
-    It fixes which rank owns which optimizer slots, so it must not change during a run."""
-    return int(os.environ.get('AGX_DP_CHUNKS', '4'))
+def _dp_chunks(net=None, B=None):
+    """Pieces of the data-parallel exchange of `net` (0 or 1 = one piece: the flat one-shard-per-rank layout).
+    AGX_DP_CHUNKS if set; otherwise 4 from 128 rows per GPU on - the row chunks of the largest weight-gradient product
+    (164 us at 512 rows) then cover most of the earlier pieces' exchange - and ONE piece below: at 32 rows that product
+    takes 22 us, nothing can hide behind it, and every further piece costs two more collectives per step.
+    The choice fixes which rank owns which optimizer slots, so it is made at the network's first data-parallel step
+    and kept on the network for the rest of the run."""
+    kept = getattr(net, '_dp_pieces', None) if net is not None else None
+    if kept is not None:
+        return kept
+    env = os.environ.get('AGX_DP_CHUNKS')
+    n = int(env) if env is not None else (4 if (B is not None and B >= 128) else 1)
+    if net is not None and B is not None:
+        net._dp_pieces = n
+    return n
 
 
 def _big_kernel(net):
@@ -782,7 +793,7 @@ def _dp_native_iteration(x, cc, nc, gen, disc, gen_opt, disc_opt, nb_critic, gp_
     a = _lib.DpArgs()
     keep = []
     for net, opt, dst in ((disc, disc_opt, a.disc), (gen, gen_opt, a.gen)):
-        rows, pieces = _exchange_plan(net, world, _dp_chunks())
+        rows, pieces = _exchange_plan(net, world, _dp_chunks(net, B))
         if len(pieces) > _lib.AGX_MAX_DP_PIECES:
             raise ValueError('AGX_DP_CHUNKS: at most %d pieces' % _lib.AGX_MAX_DP_PIECES)
         dst.n_pieces = len(pieces)
@@ -823,7 +834,7 @@ def _dp_update(net, opt):
     links as one all-reduce of the gradients.  The loss scalars sit in the slots behind the gradients: their
     sums travel back in the parameter buffer's tail (net._pbuf[n_flat:])."""
     world, rank = _world()
-    pieces = _exchange_pieces(net, world, _dp_chunks())
+    pieces = _exchange_pieces(net, world, _dp_chunks(net, 0))   # (no overlap on this path: one piece unless AGX_DP_CHUNKS asks)
     key = (world, rank, len(pieces))
     bufs = net._shards.get(key)
     if bufs is None:
@@ -858,7 +869,7 @@ def _gathered_slot(net, slot):
         return slot
     total = _exchange_layout(net, world, rank)[0]
     full = torch.zeros(total, dtype=slot.dtype, device=slot.device)
-    for start, per in _exchange_pieces(net, world, _dp_chunks()):
+    for start, per in _exchange_pieces(net, world, _dp_chunks(net)):
         lo = start + rank * per
         mine = torch.zeros(per, dtype=slot.dtype, device=slot.device)
         n = max(0, min(lo + per, net.n_flat) - lo)
