@@ -117,10 +117,12 @@ struct LrTable {
   float v[64];
 };
 // (X2: optional second stacked-input buffer that receives the same real rows)
+struct StageDraws;
 int iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2, int ldx, int G, int B, const int32_t *cat,
                int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
                uint64_t rng_offset, float **loss_slot, float *losses_out, const LrTable *lrs, float *lr_dev,
-               const float *aug_mask = nullptr, const float *aug_noise = nullptr, int aug_ldn = 0);
+               const float *aug_mask = nullptr, const float *aug_noise = nullptr, int aug_ldn = 0,
+               const StageDraws *sd = nullptr);
 // (aug_mask: the staged real rows get + aug_mask[b] * aug_noise[b * aug_ldn + g], tf_utils.py:210)
 // All the draws of a captured iteration AND the generator's layer-1 input in ONE launch: segment i fills
 // n values from stream position *base_dev + sub_offset (element skip + j) into out, as rows of `cols` values
@@ -149,6 +151,22 @@ struct CriticCov {
 int iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const IterDraws &d, const agx_embed_t *e,
                const float *tables, const float *num, int n_num, const int32_t *cat, int ld_cat, int B, int rows_cov,
                int zcols, float *gin0, int ldg0, const CriticCov *xc = nullptr);
+// The same draws as block rows BEHIND the staging launch of a replayed one-GPU iteration (one launch less per
+// iteration): iter_draws_desc validates and packs what iter_draws would launch, iter_stage(..., sd) launches both.
+// The draws then take the stream position from the launch argument and the covariates from the caller's arrays
+// (the staged copies are written by the same launch).
+struct StageDraws {
+  int on;                       // 0: nothing packed (iter_stage launches the staging rows only)
+  IterDraws d;
+  unsigned long long seed;
+  agx_embed_t e, e2;
+  const float *tables, *tables2;
+  int n_num, ld_cat, B, rows_cov, zcols, ldg0, ncov, cov_row, ldx, xcol0, xrows, ncov2;
+  float *gin0, *X;
+  int gx, rows;                 // grid of the draws part: gx blocks along x, `rows` block rows
+};
+int iter_draws_desc(uint64_t seed, const IterDraws &d, const agx_embed_t *e, const float *tables, int n_num, int ld_cat,
+                    int B, int rows_cov, int zcols, float *gin0, int ldg0, const CriticCov *xc, StageDraws *out);
 // Adam with the bias-corrected step size read from device memory (captured iterations)
 int opt_adam_dev_lr(void *stream, float *w, const float *g, float *m, float *v, int64_t n, const float *lr_dev,
                     float beta1, float beta2, float eps);

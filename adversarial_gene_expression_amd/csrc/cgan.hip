@@ -771,6 +771,7 @@ struct agx_iter_graph {
   bool chainx = false; // real rows are staged into both stacked-input buffers (chain_input)
   const float *aug_mask = nullptr, *aug_noise_real = nullptr;   // augmentation of the staged real rows (trace constants)
   agx::LrTable lrs;    // Adam: step sizes for the next replay (agx_cgan_iter_set_lr)
+  agx::StageDraws sd = {};   // one-graph iterations: the draws ride the staging launch in front of the graph (sd.on)
   int split = 0, B_global = 0;
   // agx_cgan_dp_iteration: one event per row chunk of the large product + "exchange of the step done"
   hipEvent_t ev_chunk[AGX_MAX_DP_PIECES] = {};
@@ -806,7 +807,23 @@ bool chain_input(const agx_cgan *h, const agx_iter_args_t *a) {
 // (nbc == 0: segment 0 holds the generator gradients).
 // split == 2: the segments hold NO optimizer launch (nbc+1 segments): the caller reduce-scatters the
 // gradient buffer, updates its 1/R shard of the parameters and all-gathers them between segments.
-int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int seg, int64_t *draws) {
+// Where the iteration's draws go when they can ride the staging launch (one-GPU iterations, iter_stage(..., sd)):
+// sd_out (capture): packed for the launch that precedes every replay, nothing recorded; launch (eager): the staging
+// launch itself is issued here, with the draws when they fit one launch and without otherwise.
+struct StageHook {
+  agx::StageDraws *sd_out = nullptr;
+  bool launch = false;
+  const float *x = nullptr;
+  int ldx = 0;
+  const int32_t *cat = nullptr;
+  const float *num = nullptr;
+  uint64_t rng_offset = 0;
+  float *losses_out = nullptr;
+  const agx::LrTable *lrs = nullptr;
+};
+
+int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int seg, int64_t *draws,
+                     const StageHook *hook = nullptr) {
   const int B = a->B, Z = h->cfg.z_dim, nbc = a->nb_critic, S = nbc + 1, G = h->G;
   const int Bg = a->B_global > 0 ? a->B_global : B, lo = a->row_lo;
   const agx_mlp_desc_t &dm = h->cfg.disc;
@@ -853,6 +870,12 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   //  186.4 k against 189.6 k samples/s)
   const bool fold0 = chainx0 && nbc > 0 && !a->aug_mask_disc && B <= 64 && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
                      agx::gemm_can_dual(S * B, gm0.dims[Lg0 + 1], gm0.dims[Lg0], h->skws_floats, 0);
+  auto stage_now = [&](const agx::StageDraws *sd) -> int {
+    const int ncat = gm0.emb.n_cat, nnum = gm0.n_num;
+    return agx::iter_stage(st, hook->x, hook->ldx, h->Xbuf[0], chain_input(h, a) ? h->Xbuf[1] : nullptr, h->ldx, h->G, B,
+                           hook->cat, h->scat, B * ncat, hook->num, h->snum, B * nnum, h->rngpos, hook->rng_offset,
+                           h->loss_slot, hook->losses_out, hook->lrs, h->lrdev, a->aug_mask_disc, a->aug_noise_real, h->G, sd);
+  };
   // draws + generator input in one launch (z straight into the [z | num | emb] rows) when the segment list fits
   static const bool draw_fuse_on = getenv("AGX_NO_DRAW_FUSE") == nullptr;
   const bool draw_fuse = draw_fuse_on && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS;
@@ -873,10 +896,21 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     if (fold0) {
       xc.e = &dm.emb; xc.tables = h->dp; xc.X = h->Xbuf[0]; xc.ldx = h->ldx; xc.col0 = G; xc.rows = 2 * B;
     }
-    if (in_seg(0))
-      AGX_TRY(agx::iter_draws(st, a->seed, h->rngpos, dr, &gm0.emb, h->gp, h->snum, gm0.n_num, h->scat, gm0.emb.n_cat, B,
-                              S * B, Z, h->gin0, h->ldg0, fold0 ? &xc : nullptr));
+    static const bool merge_draws = getenv("AGX_NO_STAGE_DRAWS") == nullptr;   // (cross-check knob, tests/test_gpu_knobs.py)
+    if (hook && seg < 0 && merge_draws) {
+      agx::StageDraws local;
+      agx::StageDraws *sd = hook->sd_out ? hook->sd_out : &local;
+      AGX_TRY(agx::iter_draws_desc(a->seed, dr, &gm0.emb, h->gp, gm0.n_num, gm0.emb.n_cat, B, S * B, Z, h->gin0, h->ldg0,
+                                   fold0 ? &xc : nullptr, sd));
+      if (hook->launch) AGX_TRY(stage_now(sd));
+    } else {
+      if (hook && hook->launch) AGX_TRY(stage_now(nullptr));
+      if (in_seg(0))
+        AGX_TRY(agx::iter_draws(st, a->seed, h->rngpos, dr, &gm0.emb, h->gp, h->snum, gm0.n_num, h->scat, gm0.emb.n_cat, B,
+                                S * B, Z, h->gin0, h->ldg0, fold0 ? &xc : nullptr));
+    }
   } else {
+    if (hook && hook->launch) AGX_TRY(stage_now(nullptr));
     // every draw of the iteration in one launch (per 16 segments), at the stream positions the eager
     // entry points use for the GLOBAL batch (z_k then alpha_k per critic step, then the generator
     // step's z); a rank keeps rows [lo, lo+B) of each draw
@@ -1014,7 +1048,9 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
       agx::set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
       return AGX_E_HIP;
     }
-    int rc = record_iteration(h, st, a, a->split ? s : -1, &g->draws);
+    StageHook hook;
+    hook.sd_out = &g->sd;
+    int rc = record_iteration(h, st, a, a->split ? s : -1, &g->draws, !a->split ? &hook : nullptr);
     e = hipStreamEndCapture(st, &g->graph[s]);
     g->nseg = s + 1;
     if (rc != AGX_OK) {
@@ -1052,7 +1088,7 @@ extern "C" int agx_cgan_iter_stage(agx_iter_graph_t *g, void *stream, const floa
   }
   return agx::iter_stage(st, x, ldx, h->Xbuf[0], g->chainx ? h->Xbuf[1] : nullptr, h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum, B * nnum,
                          h->rngpos, rng_offset, h->loss_slot, nullptr, g->adam ? &g->lrs : nullptr, h->lrdev,
-                         g->aug_mask, g->aug_noise_real, h->G);
+                         g->aug_mask, g->aug_noise_real, h->G, g->sd.on ? &g->sd : nullptr);
 }
 
 extern "C" int32_t agx_cgan_iter_num_segs(const agx_iter_graph_t *g) { return g ? g->nseg : 0; }
@@ -1080,7 +1116,7 @@ extern "C" int agx_cgan_iter_launch(agx_iter_graph_t *g, void *stream, const flo
     }
     AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], g->chainx ? h->Xbuf[1] : nullptr, h->ldx, h->G, B, cat, h->scat, B * ncat, num, h->snum,
                             B * nnum, h->rngpos, rng_offset, h->loss_slot, losses_out, g->adam ? &g->lrs : nullptr,
-                            h->lrdev, g->aug_mask, g->aug_noise_real, h->G));
+                            h->lrdev, g->aug_mask, g->aug_noise_real, h->G, g->sd.on ? &g->sd : nullptr));
     for (int s = 0; s < g->nseg; ++s) AGX_HIP(hipGraphLaunch(g->exec[s], st));
     return AGX_OK;
   }
@@ -1123,11 +1159,14 @@ extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_a
   AGX_CHECK_ARG((ncat == 0 || cat) && (nnum == 0 || num), "agx_cgan_iter_eager: covariates missing");
   hipStream_t st = agx::as_stream(stream);
   const bool snap = !a->disc_losses && !a->gen_losses;
-  AGX_TRY(agx::iter_stage(st, x, ldx, h->Xbuf[0], chain_input(h, a) ? h->Xbuf[1] : nullptr, h->ldx, h->G, a->B, cat, h->scat, a->B * ncat, num, h->snum,
-                          a->B * nnum, h->rngpos, rng_offset, h->loss_slot, snap ? losses_out : nullptr,
-                          lrs.n ? &lrs : nullptr, h->lrdev, a->aug_mask_disc, a->aug_noise_real, h->G));
+  // (the staging launch is issued inside record_iteration, where the iteration's draws join it)
+  StageHook hook;
+  hook.launch = true;
+  hook.x = x; hook.ldx = ldx; hook.cat = cat; hook.num = num; hook.rng_offset = rng_offset;
+  hook.losses_out = snap ? losses_out : nullptr;
+  hook.lrs = lrs.n ? &lrs : nullptr;
   int64_t draws = 0;
-  AGX_TRY(record_iteration(h, st, a, -1, &draws));
+  AGX_TRY(record_iteration(h, st, a, -1, &draws, &hook));
   if (draws_out) *draws_out = draws;
   return AGX_OK;
 }

@@ -422,19 +422,20 @@ __global__ void __launch_bounds__(256) rng_multi_kernel(const RngSegs segs, unsi
 }
 
 // draws of a whole iteration + covariate columns of the generator input (agx::iter_draws)
-__global__ void __launch_bounds__(256) iter_draws_kernel(const agx::IterDraws d, unsigned long long seed,
-                                                         const unsigned long long *__restrict__ base_dev,
-                                                         agx_embed_t e, const float *__restrict__ tables,
-                                                         const float *__restrict__ num, int n_num,
-                                                         const int *__restrict__ cat, int ld_cat, int B, int rows_cov,
-                                                         int zcols, float *__restrict__ gin0, int ldg0, int ncov,
-                                                         int gen_cov_row, agx_embed_t e2, const float *__restrict__ tables2,
-                                                         float *__restrict__ X, int ldx, int xcol0, int xrows, int ncov2) {
-  if ((int)blockIdx.y >= d.n + gen_cov_row) {
+// (bx, by, gx: block coordinates and x extent of the draws grid - its own launch, or block rows behind the staging rows)
+__device__ __forceinline__ void iter_draws_body(const agx::IterDraws &d, unsigned long long seed, unsigned long long base,
+                                                const agx_embed_t &e, const float *__restrict__ tables,
+                                                const float *__restrict__ num, int n_num,
+                                                const int *__restrict__ cat, int ld_cat, int B, int rows_cov,
+                                                int zcols, float *__restrict__ gin0, int ldg0, int ncov,
+                                                int gen_cov_row, const agx_embed_t &e2, const float *__restrict__ tables2,
+                                                float *__restrict__ X, int ldx, int xcol0, int xrows, int ncov2,
+                                                int bx, int by, int gx) {
+  if (by >= d.n + gen_cov_row) {
     // covariate columns of the stacked critic input, from the critic's tables (as stack_rows_kernel writes them)
     const long long total = (long long)xrows * ncov2;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = (long long)bx * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gx * blockDim.x) {
       const int r = (int)(idx / ncov2), b = r % B;
       int c = (int)(idx % ncov2);
       float v = 0.f;
@@ -455,18 +456,18 @@ __global__ void __launch_bounds__(256) iter_draws_kernel(const agx::IterDraws d,
     }
     return;
   }
-  if ((int)blockIdx.y < d.n) {
-    const agx::DrawSeg sg = d.seg[blockIdx.y];
-    const unsigned long long offset = sg.sub_offset + (base_dev ? *base_dev : 0ull);
-    const long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long qs = (long long)gridDim.x * blockDim.x;
+  if (by < d.n) {
+    const agx::DrawSeg sg = d.seg[by];
+    const unsigned long long offset = sg.sub_offset + base;
+    const long long q0 = (long long)bx * blockDim.x + threadIdx.x;
+    const long long qs = (long long)gx * blockDim.x;
     if (sg.normal) rng_fill<true>(sg.out, sg.n, seed, offset, q0, qs, sg.skip, sg.cols, sg.ld);
     else rng_fill<false>(sg.out, sg.n, seed, offset, q0, qs, sg.skip, sg.cols, sg.ld);
     return;
   }
   const long long total = (long long)rows_cov * ncov;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx = (long long)bx * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gx * blockDim.x) {
     const int r = (int)(idx / ncov), b = r % B;
     int c = (int)(idx % ncov);
     float v = 0.f;
@@ -485,6 +486,18 @@ __global__ void __launch_bounds__(256) iter_draws_kernel(const agx::IterDraws d,
     }
     gin0[(size_t)r * ldg0 + zcols + (int)(idx % ncov)] = v;
   }
+}
+
+__global__ void __launch_bounds__(256) iter_draws_kernel(const agx::IterDraws d, unsigned long long seed,
+                                                         const unsigned long long *__restrict__ base_dev,
+                                                         agx_embed_t e, const float *__restrict__ tables,
+                                                         const float *__restrict__ num, int n_num,
+                                                         const int *__restrict__ cat, int ld_cat, int B, int rows_cov,
+                                                         int zcols, float *__restrict__ gin0, int ldg0, int ncov,
+                                                         int gen_cov_row, agx_embed_t e2, const float *__restrict__ tables2,
+                                                         float *__restrict__ X, int ldx, int xcol0, int xrows, int ncov2) {
+  iter_draws_body(d, seed, base_dev ? *base_dev : 0ull, e, tables, num, n_num, cat, ld_cat, B, rows_cov, zcols, gin0, ldg0,
+                  ncov, gen_cov_row, e2, tables2, X, ldx, xcol0, xrows, ncov2, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -896,20 +909,19 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const SmallPlan plan,
 // One launch in front of a replayed iteration: real rows -> rows [0,B) of the stacked critic input,
 // covariates -> staging, RNG stream position and the loss-snapshot address -> device memory.
 template <bool AUG>
-__global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict__ x, int ldxs,
-                                                         float *__restrict__ X, float *__restrict__ X2, int ldx, int G, int vec,
-                                                         const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
-                                                         const float *__restrict__ num, float *__restrict__ snum, int n_num,
-                                                         unsigned long long *rngpos, unsigned long long rng_offset,
-                                                         float **loss_slot, float *losses_out,
-                                                         const agx::LrTable lrs, float *__restrict__ lr_dev,
-                                                         const float *__restrict__ aug_mask,
-                                                         const float *__restrict__ aug_noise, int aug_ldn) {
-  const int b = blockIdx.y;
+__device__ __forceinline__ void iter_stage_body(const float *__restrict__ x, int ldxs,
+                                                float *__restrict__ X, float *__restrict__ X2, int ldx, int G, int vec,
+                                                const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
+                                                const float *__restrict__ num, float *__restrict__ snum, int n_num,
+                                                unsigned long long *rngpos, unsigned long long rng_offset,
+                                                float **loss_slot, float *losses_out,
+                                                const agx::LrTable &lrs, float *__restrict__ lr_dev,
+                                                const float *__restrict__ aug_mask,
+                                                const float *__restrict__ aug_noise, int aug_ldn, int bx, int b, int gx) {
   const float *s = x + (size_t)b * ldxs;
   float *d = X + (size_t)b * ldx;
   float *d2 = X2 ? X2 + (size_t)b * ldx : nullptr;
-  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = gx * blockDim.x, t0 = bx * blockDim.x + threadIdx.x;
   if (AUG) {   // augmented real rows (same expression as aug_add_kernel on the staged row)
     const float m = aug_mask[b];
     const float *nz = aug_noise + (size_t)b * aug_ldn;
@@ -935,7 +947,7 @@ __global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict
       if (d2) d2[g] = s[g];
     }
   }
-  if (blockIdx.x == 0 && b == 0) {
+  if (bx == 0 && b == 0) {
     for (int i = threadIdx.x; i < n_cat; i += blockDim.x) scat[i] = cat[i];
     for (int i = threadIdx.x; i < n_num; i += blockDim.x) snum[i] = num[i];
     if (threadIdx.x == 0) {
@@ -944,6 +956,46 @@ __global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict
     }
     if ((int)threadIdx.x < lrs.n) lr_dev[threadIdx.x] = lrs.v[threadIdx.x];
   }
+}
+
+template <bool AUG>
+__global__ void __launch_bounds__(256) iter_stage_kernel(const float *__restrict__ x, int ldxs,
+                                                         float *__restrict__ X, float *__restrict__ X2, int ldx, int G, int vec,
+                                                         const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
+                                                         const float *__restrict__ num, float *__restrict__ snum, int n_num,
+                                                         unsigned long long *rngpos, unsigned long long rng_offset,
+                                                         float **loss_slot, float *losses_out,
+                                                         const agx::LrTable lrs, float *__restrict__ lr_dev,
+                                                         const float *__restrict__ aug_mask,
+                                                         const float *__restrict__ aug_noise, int aug_ldn) {
+  iter_stage_body<AUG>(x, ldxs, X, X2, ldx, G, vec, cat, scat, n_cat, num, snum, n_num, rngpos, rng_offset, loss_slot,
+                       losses_out, lrs, lr_dev, aug_mask, aug_noise, aug_ldn, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// staging rows [0, B) of the grid's y axis, the iteration's draws (iter_draws_body) in the block rows behind them:
+// the draws read the stream position and the covariates from the launch arguments, not from what the staging rows
+// write, so the two parts share nothing inside the launch
+template <bool AUG>
+__global__ void __launch_bounds__(256) iter_stage_draws_kernel(const float *__restrict__ x, int ldxs,
+                                                               float *__restrict__ X, float *__restrict__ X2, int ldx, int G, int vec,
+                                                               const int *__restrict__ cat, int *__restrict__ scat, int n_cat,
+                                                               const float *__restrict__ num, float *__restrict__ snum, int n_num,
+                                                               unsigned long long *rngpos, unsigned long long rng_offset,
+                                                               float **loss_slot, float *losses_out,
+                                                               const agx::LrTable lrs, float *__restrict__ lr_dev,
+                                                               const float *__restrict__ aug_mask,
+                                                               const float *__restrict__ aug_noise, int aug_ldn, int B, int gxs,
+                                                               const agx::StageDraws sd) {
+  if ((int)blockIdx.y < B) {
+    if ((int)blockIdx.x < gxs)
+      iter_stage_body<AUG>(x, ldxs, X, X2, ldx, G, vec, cat, scat, n_cat, num, snum, n_num, rngpos, rng_offset, loss_slot,
+                           losses_out, lrs, lr_dev, aug_mask, aug_noise, aug_ldn, (int)blockIdx.x, (int)blockIdx.y, gxs);
+    return;
+  }
+  if ((int)blockIdx.x < sd.gx)
+    iter_draws_body(sd.d, sd.seed, rng_offset, sd.e, sd.tables, num, sd.n_num, cat, sd.ld_cat, sd.B, sd.rows_cov, sd.zcols,
+                    sd.gin0, sd.ldg0, sd.ncov, sd.cov_row, sd.e2, sd.tables2, sd.X, sd.ldx, sd.xcol0, sd.xrows, sd.ncov2,
+                    (int)blockIdx.x, (int)blockIdx.y - B, sd.gx);
 }
 
 inline int grid_for(long long n, int per_block = 256, int cap = 4096) {
@@ -1220,6 +1272,45 @@ extern "C" int agx_rng_multi(void *stream, uint64_t seed, const uint64_t *base_d
   return AGX_OK;
 }
 
+int agx::iter_draws_desc(uint64_t seed, const agx::IterDraws &d, const agx_embed_t *e, const float *tables, int n_num,
+                         int ld_cat, int B, int rows_cov, int zcols, float *gin0, int ldg0, const agx::CriticCov *xc,
+                         agx::StageDraws *out) {
+  AGX_CHECK_ARG(out && d.n > 0 && d.n <= AGX_MAX_RNG_SEGS && e && gin0 && B > 0 && rows_cov >= 0, "iter_draws_desc: bad argument");
+  out->on = 0;
+  long long nmax = 0;
+  for (int i = 0; i < d.n; ++i) {
+    AGX_CHECK_ARG(d.seg[i].out && d.seg[i].n >= 0 && d.seg[i].skip >= 0 && (d.seg[i].sub_offset & 3) == 0 &&
+                      (d.seg[i].cols == 0 || d.seg[i].ld >= d.seg[i].cols), "iter_draws_desc: segment %d", i);
+    nmax = std::max<long long>(nmax, d.seg[i].n + 3);
+  }
+  int ncov = n_num;
+  for (int i = 0; i < e->n_cat; ++i) ncov += e->edim[i];
+  AGX_CHECK_ARG(ldg0 >= zcols + ncov && (e->n_cat == 0 || (tables && ld_cat >= e->n_cat)), "iter_draws_desc: generator input description");
+  const int cov_row = (rows_cov > 0 && ncov > 0) ? 1 : 0;
+  agx_embed_t e2 = {};
+  int ncov2 = 0, x_row = 0;
+  if (xc && xc->rows > 0) {
+    AGX_CHECK_ARG(xc->e && xc->X && xc->e->n_cat == e->n_cat && (xc->e->n_cat == 0 || xc->tables),
+                  "iter_draws_desc: critic covariate description");
+    e2 = *xc->e;
+    ncov2 = n_num;
+    for (int i = 0; i < e2.n_cat; ++i) ncov2 += e2.edim[i];
+    AGX_CHECK_ARG(xc->ldx >= xc->col0 + ncov2, "iter_draws_desc: critic input too narrow");
+    x_row = ncov2 > 0 ? 1 : 0;
+  }
+  const long long cov_work = std::max<long long>((long long)rows_cov * ncov, x_row ? (long long)xc->rows * ncov2 : 0);
+  out->d = d; out->seed = seed; out->e = *e; out->e2 = e2;
+  out->tables = tables; out->tables2 = x_row ? xc->tables : nullptr;
+  out->n_num = n_num; out->ld_cat = ld_cat; out->B = B; out->rows_cov = rows_cov; out->zcols = zcols; out->ldg0 = ldg0;
+  out->ncov = ncov; out->cov_row = cov_row;
+  out->ldx = x_row ? xc->ldx : 0; out->xcol0 = x_row ? xc->col0 : 0; out->xrows = x_row ? xc->rows : 0; out->ncov2 = ncov2;
+  out->gin0 = gin0; out->X = x_row ? xc->X : nullptr;
+  out->gx = grid_for(std::max<long long>((nmax + 3) / 4, cov_work), 256, 256);   // (the grid iter_draws launches)
+  out->rows = d.n + cov_row + x_row;
+  out->on = 1;
+  return AGX_OK;
+}
+
 int agx::iter_draws(void *stream, uint64_t seed, const uint64_t *base_dev, const agx::IterDraws &d, const agx_embed_t *e,
                     const float *tables, const float *num, int n_num, const int32_t *cat, int ld_cat, int B,
                     int rows_cov, int zcols, float *gin0, int ldg0, const agx::CriticCov *xc) {
@@ -1363,12 +1454,29 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
 int agx::iter_stage(void *stream, const float *x, int ldxs, float *X, float *X2, int ldx, int G, int B, const int32_t *cat,
                     int32_t *scat, int n_cat, const float *num, float *snum, int n_num, uint64_t *rngpos,
                     uint64_t rng_offset, float **loss_slot, float *losses_out, const agx::LrTable *lrs, float *lr_dev,
-                    const float *aug_mask, const float *aug_noise, int aug_ldn) {
+                    const float *aug_mask, const float *aug_noise, int aug_ldn, const agx::StageDraws *sd) {
   agx::LrTable none;
   none.n = 0;
   const int vec = agx::aligned16(x) && agx::aligned16(X) && (!X2 || agx::aligned16(X2)) && ldxs % 4 == 0 && ldx % 4 == 0;
   const int gx = std::max(1, std::min(8, agx::cdiv(G, 4 * 256)));
   AGX_CHECK_ARG(!aug_mask || aug_noise, "iter_stage: augmentation noise missing");
+  if (sd && sd->on) {
+    // staging rows + the iteration's draws in one launch (the draws read cat / num from the caller's arrays)
+    AGX_CHECK_ARG(sd->B == B && (sd->n_num == 0 || num) && (sd->e.n_cat == 0 || cat), "iter_stage: draws description does not match");
+    const dim3 grid(std::max(gx, sd->gx), B + sd->rows);
+    if (aug_mask)
+      hipLaunchKernelGGL(iter_stage_draws_kernel<true>, grid, dim3(256), 0, agx::as_stream(stream), x, ldxs, X, X2, ldx, G, vec,
+                         cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
+                         (unsigned long long)rng_offset, loss_slot, losses_out, (lrs && lr_dev) ? *lrs : none, lr_dev,
+                         aug_mask, aug_noise, aug_ldn, B, gx, *sd);
+    else
+      hipLaunchKernelGGL(iter_stage_draws_kernel<false>, grid, dim3(256), 0, agx::as_stream(stream), x, ldxs, X, X2, ldx, G, vec,
+                         cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),
+                         (unsigned long long)rng_offset, loss_slot, losses_out, (lrs && lr_dev) ? *lrs : none, lr_dev,
+                         nullptr, nullptr, 0, B, gx, *sd);
+    AGX_LAUNCH_CHECK();
+    return AGX_OK;
+  }
   if (aug_mask)
     hipLaunchKernelGGL(iter_stage_kernel<true>, dim3(gx, B), dim3(256), 0, agx::as_stream(stream), x, ldxs, X, X2, ldx, G, vec,
                        cat, scat, n_cat, num, snum, n_num, reinterpret_cast<unsigned long long *>(rngpos),

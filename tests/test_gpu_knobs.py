@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KNOBS = [
     ('AGX_NO_TAIL', '1'), ('AGX_NO_FUSED_OPT', '1'), ('AGX_NO_FUSED_REST', '1'), ('AGX_NO_TN_FUSE', '1'),
     ('AGX_NO_CHAIN_INPUT', '1'), ('AGX_NO_DRAW_FUSE', '1'), ('AGX_NO_GEN_TAIL', '1'), ('AGX_TAIL_NSPLIT', '1'),
-    ('AGX_TAIL_NSPLIT', '2'),
+    ('AGX_TAIL_NSPLIT', '2'), ('AGX_NO_STAGE_DRAWS', '1'),
 ]
 
 
