@@ -80,6 +80,10 @@ struct TailArgs {
   // A2 = act(A1 . W2 + b2) over rows [0, m_slab); K_in <= 128
   const float *in; int ld_in, K_in;
   const float *W1; int ldw1;
+  // mode 3 (generator backward behind the output layer's delta slabs): A1 = act'(M1) * sum_z slab_z  (delta of the
+  // last hidden layer, width H1), A2 = act'(M2) * (A1 . W2^T)  (delta of the layer before, width H2; W2 is that
+  // layer's kernel [H2, H1], ldw2 >= H1); M1 / M2 = the layers' activations (ReLU masks)
+  const float *M1; int ldm1; const float *M2; int ldm2;
 };
 int critic_tail(void *stream, int mode, const TailArgs &a);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused

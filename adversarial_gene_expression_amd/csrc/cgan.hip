@@ -565,6 +565,10 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   tn.n = 0;
   const float *dout = dX;
   int lddout = ldx;
+  // small batches of the two-hidden-layer generator: split-K reduce + hidden delta product as one tail launch
+  static const bool gen_tail_off = getenv("AGX_NO_GEN_TAIL") != nullptr;
+  const bool tail3 = !gen_tail_off && Lg == 2 && !gm.bn && B <= 64 && gm.dims[1] <= 256 && gm.dims[2] <= 256 &&
+                     gm.ldw[1] % 4 == 0;
   for (int l = Lg; l >= 0; --l) {
     const float *in = l == 0 ? h->gin0 + (size_t)gen_row0 * h->ldg0 : h->gh[l] + (size_t)gen_row0 * h->ldgh[l];
     const int ldin = l == 0 ? h->ldg0 : h->ldgh[l];
@@ -590,7 +594,26 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     j.cs_A[j.n_colsum] = dout; j.cs_lda[j.n_colsum] = lddout; j.cs_r0[j.n_colsum] = 0; j.cs_r1[j.n_colsum] = B;
     j.cs_H[j.n_colsum] = gm.dims[l + 1]; j.cs_out[j.n_colsum] = h->gg + gm.b_off[l];
     ++j.n_colsum;
-    if (l > 0) {
+    if (l == Lg && tail3) {
+      // the output layer's delta product leaves raw split-K slabs; one tail launch sums them, applies both ReLU masks
+      // and runs the hidden delta product between them (tail.hip mode 3): two launches less than reduce + product
+      int sk = 0;
+      Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l], gm.dims[l + 1]);
+      AGX_TRY(g.id(AGX_K_GEN_BWD_OUT).run_slabs(st, &sk));
+      agx::TailArgs t;
+      memset(&t, 0, sizeof(t));
+      t.ws = h->skws; t.splitk = sk; t.m_slab = B;
+      t.H1 = gm.dims[l]; t.H2 = gm.dims[l - 1];
+      t.W2 = h->gp + gm.w_off[l - 1]; t.ldw2 = gm.ldw[l - 1];
+      t.slope = h->cfg.slope;
+      t.A1 = h->gd[l]; t.lda1 = h->ldgh[l]; t.A2 = h->gd[l - 1]; t.lda2 = h->ldgh[l - 1];
+      t.M1 = in; t.ldm1 = ldin;
+      t.M2 = h->gh[l - 1] + (size_t)gen_row0 * h->ldgh[l - 1]; t.ldm2 = h->ldgh[l - 1];
+      t.nsplit = tail_nsplit((B + 1) / 2);
+      AGX_TRY(agx::critic_tail(st, 3, t));
+    } else if (l == Lg - 1 && tail3) {
+      // (gd[l] written by the tail launch above)
+    } else if (l > 0) {
       Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
           gm.dims[l + 1]);
       g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);

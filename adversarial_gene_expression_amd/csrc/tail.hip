@@ -9,6 +9,8 @@
 //   mode 1 (tf_utils.py:168-170 and its derivative): s = sqrt(sum rowsq) (no epsilon);
 //           f = coef*(s-1)/s; D1 *= f; E1 = act'(A1) * f * sum_z slab_z  (in place over A1);
 //           E2 = act'(A2) * (E1 . W2)  (in place over A2); covariate columns of the rows zeroed
+//   mode 3 (generator step, tf_utils.py:255 through the two hidden layers): d2 = act'(h2) * sum_z slab_z (slabs of
+//           dX . W_out^T); d1 = act'(h1) * (d2 . W_2^T) - the split-K reduce and the hidden delta product in one launch
 //
 // fp32 VALU (4 rows x 256 x 256 MACs per workgroup: nothing for MFMA to win); fixed summation
 // orders (deterministic).
@@ -152,6 +154,14 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
       }
     }
     reinterpret_cast<float *>(&a1[c])[i] = a;
+  } else if (MODE == 3) {
+    float e = 0.f;
+    if (i < nsl && c < p.H1) {
+      const float mk = p.M1[(size_t)srow(i) * p.ldm1 + c];
+      e = mk > 0.f ? v : v * p.slope;
+      if (lead) p.A1[(size_t)orow(i) * p.lda1 + c] = e;
+    }
+    reinterpret_cast<float *>(&a1[c])[i] = e;
   } else {
     float e = 0.f;
     if (i < nsl && c < p.H1) {
@@ -174,7 +184,43 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
   {
     const int jl = t % HC, q = t / HC, j = ns * HC + jl;
     float acc[TR] = {0.f, 0.f, 0.f, 0.f};
-    if (j < p.H2) {
+    if (MODE == 3) {
+      // transposed kernel: output j = row j of W2 [H2, H1] against the rows' deltas; this thread's k range of that
+      // row, contiguous: 16-byte loads, all of them in flight
+      if (j < p.H2) {
+        const int kq = (p.H1 + KQ - 1) / KQ;
+        const int k0 = q * kq, k1 = min(p.H1, k0 + kq);
+        const float *__restrict__ w = p.W2 + (size_t)j * p.ldw2;
+        int k = k0;
+        if ((p.ldw2 & 3) == 0 && (k0 & 3) == 0) {
+          for (; k + 16 <= k1; k += 16) {
+            float4 wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const float4 *>(w + k + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float ws4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float4 av = a1[k + 4 * u + e];
+                acc[0] = fmaf(av.x, ws4[e], acc[0]);
+                acc[1] = fmaf(av.y, ws4[e], acc[1]);
+                acc[2] = fmaf(av.z, ws4[e], acc[2]);
+                acc[3] = fmaf(av.w, ws4[e], acc[3]);
+              }
+            }
+          }
+        }
+        for (; k < k1; ++k) {
+          const float wv = w[k];
+          const float4 av = a1[k];
+          acc[0] = fmaf(av.x, wv, acc[0]);
+          acc[1] = fmaf(av.y, wv, acc[1]);
+          acc[2] = fmaf(av.z, wv, acc[2]);
+          acc[3] = fmaf(av.w, wv, acc[3]);
+        }
+      }
+    } else if (j < p.H2) {
       const int kq = (p.H1 + KQ - 1) / KQ;
       const int k0 = q * kq, k1 = min(p.H1, k0 + kq);
       const float *__restrict__ w = p.W2 + (size_t)k0 * p.ldw2 + j;
@@ -234,6 +280,9 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
       const float wv = p.w3[c], dv = cc * wv;
       p.D2[(size_t)row * p.ldd2 + c] = a > 0.f ? dv : dv * p.slope;
       hp = a * wv;
+    } else if (MODE == 3) {
+      const float mk = p.M2[(size_t)srow(i) * p.ldm2 + c];
+      p.A2[o] = mk > 0.f ? x : x * p.slope;
     } else {
       p.A2[o] = p.A2[o] > 0.f ? x : x * p.slope;
     }
@@ -259,9 +308,9 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
 int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
   agx::TailArgs a = a_in;
   AGX_CHECK_ARG((mode == 2 || (a.ws && a.splitk >= 1)) && a.m_slab >= 1 && a.H1 >= 1 && a.H1 <= TW && a.H2 >= 1 && a.H2 <= TW &&
-                    a.W2 && a.ldw2 >= a.H2 && a.A1 && a.A2 && a.lda1 >= a.H1 && a.lda2 >= a.H2,
+                    a.W2 && a.ldw2 >= (mode == 3 ? a.H1 : a.H2) && a.A1 && a.A2 && a.lda1 >= a.H1 && a.lda2 >= a.H2,
                 "critic_tail: bad shapes (H1=%d H2=%d m=%d)", a.H1, a.H2, a.m_slab);
-  AGX_CHECK_ARG(a.nsplit == 0 || a.nsplit == 1 || mode == 2 || ((a.nsplit == 2 || a.nsplit == 4) && a.out_ld > 0 && (mode == 0 || a.A1m)),
+  AGX_CHECK_ARG(a.nsplit == 0 || a.nsplit == 1 || mode == 2 || mode == 3 || ((a.nsplit == 2 || a.nsplit == 4) && a.out_ld > 0 && (mode == 0 || a.A1m)),
                 "critic_tail: column split %d needs out_ld and the mask copy", a.nsplit);
   hipStream_t st = agx::as_stream(stream);
   // rows per workgroup: every workgroup pulls all of W2 (256 KB at 64 B/clk: 1.7 us) whatever its row count, so
@@ -281,6 +330,18 @@ int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
     if (a.nsplit == 4) hipLaunchKernelGGL((critic_tail_kernel<2, 4>), dim3(blocks, 4), dim3(1024), 0, st, a);
     else if (a.nsplit == 2) hipLaunchKernelGGL((critic_tail_kernel<2, 2>), dim3(blocks, 2), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((critic_tail_kernel<2, 1>), dim3(blocks), dim3(1024), 0, st, a);
+  } else if (mode == 3) {
+    AGX_CHECK_ARG(a.M1 && a.M2 && a.ldm1 >= a.H1 && a.ldm2 >= a.H2 && agx::aligned16(a.W2) &&
+                      (a.nsplit == 1 || a.nsplit == 2 || a.nsplit == 4),
+                  "critic_tail: generator backward arguments");
+    a.interp_rows = 0;
+    a.row0 = 0;
+    agx::ProfScope prof(st, AGX_K_GEN_BWD_HID, 2.0 * a.m_slab * a.H1 * (double)a.H2,
+                        4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));
+    const int blocks = agx::cdiv(a.m_slab, a.rpw);
+    if (a.nsplit == 4) hipLaunchKernelGGL((critic_tail_kernel<3, 4>), dim3(blocks, 4), dim3(1024), 0, st, a);
+    else if (a.nsplit == 2) hipLaunchKernelGGL((critic_tail_kernel<3, 2>), dim3(blocks, 2), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((critic_tail_kernel<3, 1>), dim3(blocks), dim3(1024), 0, st, a);
   } else if (mode == 0) {
     AGX_CHECK_ARG(a.b1 && a.b2 && a.w3 && a.b3 && a.D2 && a.out && a.ldd2 >= a.H2 &&
                       (a.interp_rows == 0 || (a.alpha && a.m_slab == 2 * a.interp_rows)),
