@@ -596,7 +596,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     ++j.n_colsum;
     if (l == Lg && tail3) {
       // the output layer's delta product leaves raw split-K slabs; one tail launch sums them, applies both ReLU masks
-      // and runs the hidden delta product between them (tail.hip mode 3): two launches less than reduce + product
+      // and runs the hidden delta product between them (tail.hip mode 3): one launch instead of reduce + product
       int sk = 0;
       Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l], gm.dims[l + 1]);
       AGX_TRY(g.id(AGX_K_GEN_BWD_OUT).run_slabs(st, &sk));
