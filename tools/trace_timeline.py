@@ -3,7 +3,7 @@
 
     python tools/trace_timeline.py <kernel_trace.csv> [marker-kernel-substring]
 
-An iteration starts at each launch of the marker kernel (default: iter_stage_kernel, the first
+An iteration starts at each launch of the marker kernel (default: iter_stage*, the first
 node queued by agx_cgan_iter_launch).  Prints per-kernel duration, the gap to the previous
 kernel's end, grid and register use, then totals (busy vs gaps).
 """
@@ -20,7 +20,7 @@ def short(name):
 
 def main():
     path = sys.argv[1]
-    marker = sys.argv[2] if len(sys.argv) > 2 else 'iter_stage_kernel'
+    marker = sys.argv[2] if len(sys.argv) > 2 else 'iter_stage'
     rows = []
     if path.endswith('.db'):       # rocprofv3 default output (rocpd sqlite)
         import sqlite3
