@@ -822,22 +822,30 @@ gemm_kernel(const KParams p) {
   AGX_STAMP(2);
   if (SK && !sk_last) {
     // this share ends inside the tile: publish the accumulators as this workgroup's partial tile
-    float4 *part = reinterpret_cast<float4 *>(p.sk_part) + (size_t)blockIdx.x * (BM * BN / 4);
+    // WRITE-THROUGH (sc1) 16-byte stores: the partial leaves this XCD's L2 as it is stored, so the hand-off needs no
+    // release fence - an agent-scope release is a write-back of the XCD's whole L2 (buffer_wbl2; MI355X_MICROARCH.md,
+    // visibility table): 162 -> 150.6 us on the 512-row dW_1, and 80 -> 45 us for a stream-K tail launch under a fused
+    // epilogue, whose L2 is full of freshly updated weights (profiles/r03_hybrid_streamk.txt)
+    typedef unsigned sk_u32x4 __attribute__((ext_vector_type(4)));
+    float *pbase = p.sk_part + (size_t)blockIdx.x * (BM * BN);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(pbase, 0, BM * BN * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          part[((i * TN + j) * 4 + q) * NT + tid] =
-              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        for (int q = 0; q < 4; ++q) {
+          sk_u32x4 v;
+          v.x = __float_as_uint(acc[i][j][4 * q]);
+          v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+          v.z = __float_as_uint(acc[i][j][4 * q + 2]);
+          v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (((i * TN + j) * 4 + q) * NT + tid) * 16, 0, 16);   // aux 16 = sc1
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0)   // (an agent-scope atomic store is an sc1 store)
       __hip_atomic_store(p.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     continue;   // (only the first share a workgroup computes can stop short of its tile's end)
   }
   if (SK && !sk_first) {
