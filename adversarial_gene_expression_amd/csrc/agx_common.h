@@ -84,8 +84,14 @@ struct TailArgs {
   // last hidden layer, width H1), A2 = act'(M2) * (A1 . W2^T)  (delta of the layer before, width H2; W2 is that
   // layer's kernel [H2, H1], ldw2 >= H1); M1 / M2 = the layers' activations (ReLU masks)
   const float *M1; int ldm1; const float *M2; int ldm2;
+  // mode 1, Gram form (cgan.hip critic_core): the ONE "slab" is T = d_1 . (W_g^T W_g) of the rows; the squared slope
+  // is the row's dot product of T with d_1 (rowsq unused); gU / gF (ld ldg) receive d_1 and f*d_1 for the
+  // S = d_1^T diag(f) d_1 product and D1 is left alone
+  int gram; float *gU, *gF; int ldg;
 };
 int critic_tail(void *stream, int mode, const TailArgs &a);
+// rows [0, H) of Xt <- W[0:G, 0:H]^T, their covariate columns [G, G + ncov) <- 0 (elementwise.hip; Gram form of the penalty)
+int wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused
 // epilogue, without split-K (then fused and unfused runs sum in the same order: bit-identical)
 bool gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats);

@@ -49,6 +49,10 @@ struct agx_cgan {
   float *A1m = nullptr;                     // [Bm, ldh[1]]
   float *fscale = nullptr, *rowsq = nullptr;  // [Bm], [Bm, nslab]
   int nslab = 0;
+  // Gram form of the penalty (critic_core): W_g^T W_g [H1, ldh1]; d_1 . (W_g^T W_g) [Bm, H1] (compact: read as a slab);
+  // d_1 and f*d_1 of the interpolated rows [Bm, ldh1] each
+  float *gramM = nullptr, *gramT = nullptr, *gramU = nullptr, *gramF = nullptr;
+  int dw1_rows = 0;                         // K of the critic's layer-1 weight-gradient product of the step being recorded
   float *gin0 = nullptr;                    // [S*Bm, ldg0] generator layer-1 input [z | num | emb]
   float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [S*Bm, ldgh]
   float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas      [Bm, ldgh]
@@ -144,6 +148,10 @@ void carve(agx_cgan *h, float *base) {
   h->fscale = cv.take(Bm);
   h->nslab = (c.x_dim + 31) / 32;
   h->rowsq = cv.take((int64_t)Bm * h->nslab);
+  h->gramM = cv.take((int64_t)c.disc.dims[1] * h->ldh[1]);
+  h->gramT = cv.take((int64_t)Bm * c.disc.dims[1]);
+  h->gramU = cv.take((int64_t)Bm * h->ldh[1]);
+  h->gramF = cv.take((int64_t)Bm * h->ldh[1]);
   h->gin0 = cv.take((int64_t)S * Bm * h->ldg0);
   const int Lg = c.gen.n_layers - 1;
   for (int l = 1; l <= Lg; ++l) {
@@ -190,6 +198,11 @@ void carve(agx_cgan *h, float *base) {
       need = std::max(need, agx_gemm_ws_floats(c.disc.dims[l], c.disc.dims[l + 1], 3 * B));
     }
     need = std::max(need, (int64_t)2 * B * c.disc.dims[1]);  // layer 1 always goes through the slab reduce
+    // Gram form of the penalty: W_g^T W_g, d_1 . M, d_1^T (f d_1), and the layer-1 product over 2B + H1 rows
+    need = std::max(need, agx_gemm_ws_floats(c.disc.dims[1], c.disc.dims[1], c.x_dim));
+    need = std::max(need, agx_gemm_ws_floats(B, c.disc.dims[1], c.disc.dims[1]));
+    need = std::max(need, agx_gemm_ws_floats(c.disc.dims[1], c.disc.dims[1], B));
+    need = std::max(need, agx_gemm_ws_floats(c.disc.dims[0], c.disc.dims[1], 2 * B + c.disc.dims[1]));
     for (int l = 0; l < c.gen.n_layers; ++l) {
       need = std::max(need, agx_gemm_ws_floats(B, c.gen.dims[l + 1], c.gen.dims[l]));
       need = std::max(need, agx_gemm_ws_floats(S * B, c.gen.dims[l + 1], c.gen.dims[l]));
@@ -237,6 +250,7 @@ struct Gemm {  // GEMM call builder
   Gemm &rowsq(float *q, int ld) { g.rowsq = q; g.rowsq_ld = ld; return *this; }
   Gemm &interp(int rows, const float *alpha) { g.interp_rows = rows; g.interp_alpha = alpha; return *this; }
   Gemm &id(int k) { g.prof_id = k; g.prof_tagged = 1; return *this; }
+  Gemm &force(int cfg, int splitk) { g.force_cfg = cfg; g.force_splitk = splitk; return *this; }
   Gemm &opt(const agx::FusedOpt *f) { fo = f; return *this; }
   Gemm &dual(const agx::DualOut *d) { du = d; return *this; }
   const agx::FusedOpt *fo = nullptr;
@@ -338,6 +352,23 @@ bool tail_ok(const agx_cgan *h, int rows) {
   // (mode 1 zeroes the covariate columns of a row with one 256-thread group: ncov <= 256)
   return !off && m.n_layers == 3 && m.dims[1] <= 256 && m.dims[2] <= 256 && h->ncov <= 256;
 }
+
+// Gram form of the gradient penalty (critic_core), for batches of at least 1.5 x the first hidden width: the
+// input gradient g = d_1 . W_g^T (W_g = gene rows of W_1) is never formed.  With M = W_g^T W_g [H1, H1]:
+//   |g_i|^2 = d_1i . M . d_1i^T        (tf_utils.py:168-169)
+//   (f g) . W_g = f * (d_1 . M)        (second-order chain's first product)
+//   (f g)^T d_1 = W_g . S,  S = d_1^T diag(f) d_1   (the penalty's term of dW_1)
+// so the two B x G x H1 products (and the B x G gradient, written and read back) become one H1 x H1 x G product and
+// three tiny ones, and the stacked layer-1 weight-gradient product runs over 2B + H1 rows - [real; fake; W_g^T] against
+// [D_1(real); D_1(fake); S] - instead of 3B.  Same algebra, other rounding: measured against the fp64 oracle like the
+// direct form (tests/test_gpu_fullsize.py); AGX_NO_GRAM selects the direct form (cross-check, tests/test_gpu_knobs.py).
+bool gram_ok(const agx_cgan *h, int B) {
+  static const bool off = getenv("AGX_NO_GRAM") != nullptr;
+  const agx_mlp_desc_t &m = h->cfg.disc;
+  return !off && tail_ok(h, B) && 2 * B >= 3 * m.dims[1] && B <= h->Bm;
+}
+// rows of the critic's stacked layer-1 weight-gradient product
+int dw1_rows(const agx_cgan *h, int B) { return gram_ok(h, B) ? 2 * B + h->cfg.disc.dims[1] : 3 * B; }
 
 agx::TailArgs tail_args(agx_cgan *h, int splitk, int m_slab) {
   const agx_mlp_desc_t &m = h->cfg.disc;
@@ -448,14 +479,42 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     AGX_TRY(disc_layers_from(h, st, 1, R, B, B, -invb, invb, 1.f));
   }
   AGX_TRY(disc_backward_chain(h, st, R));
+  float *D1i = h->D[1] + (size_t)2 * B * h->ldh[1];
+  const bool gram = tail && gram_ok(h, B);
+  h->dw1_rows = dw1_rows(h, B);
+  if (gram) {
+    // (see gram_ok) W_g^T into the inter rows of X; M; T = d_1 . M; one launch: slopes, f, e_1, e_2, copies of d_1
+    // and f*d_1; S into the first H1 inter rows of D_1
+    const int H1 = m.dims[1], ldh1 = h->ldh[1];
+    const float *Wg = h->dp + m.w_off[0];
+    AGX_TRY(agx::wt_rows(st, Wg, m.ldw[0], G, H1, Xi, ldx, h->ncov));
+    // (64x64 tiles over 32 K slices: 34.3 us against 40.8 for the plan's 128x128 tiles over 114 slices, whose partial
+    //  sums are 30 MB; profiles/r03_gram_form.txt)
+    Gemm gm(h, Wg, m.ldw[0], 1, Wg, m.ldw[0], 0, h->gramM, ldh1, H1, H1, G);
+    if (H1 > 128 && G >= 4096) gm.force(1, 32);
+    AGX_TRY(gm.id(AGX_K_DISC_DX).run(st));
+    AGX_TRY(Gemm(h, D1i, ldh1, 0, h->gramM, ldh1, 0, h->gramT, H1, B, H1, H1).id(AGX_K_GP2_IN).run(st));
+    agx::TailArgs t = tail_args(h, 1, B);
+    t.ws = h->gramT;
+    t.row0 = 2 * B;
+    t.slopes = h->slopes; t.fscale = h->fscale; t.D1 = h->D[1]; t.ldd1 = ldh1;
+    t.coef = gp_weight * 2.0f * invb;
+    t.A1m = h->A1m;
+    t.out_ld = 3 * h->Bm;
+    t.nsplit = tail_nsplit((B + 3) / 4);
+    t.gram = 1; t.gU = h->gramU; t.gF = h->gramF; t.ldg = ldh1;
+    AGX_TRY(agx::critic_tail(st, 1, t));
+    AGX_TRY(Gemm(h, h->gramU, ldh1, 1, h->gramF, ldh1, 0, D1i, ldh1, H1, H1, B).id(AGX_K_GP2_IN).run(st));
+  } else {
   // g = d_1 . W_1[:G]^T -> inter rows of X, with the per-slab row sums of squares as a side
   // output of the epilogue                                                      :168-169
-  float *D1i = h->D[1] + (size_t)2 * B * h->ldh[1];
   AGX_TRY(Gemm(h, D1i, h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, Xi, ldx, B, G, m.dims[1])
               .rowsq(h->rowsq, h->nslab).id(AGX_K_DISC_DX).run(st));
+  }
   // slopes; f = weight*(2/B)*(s-1)/s; D_1[inter] *= f (dg = f*g stays implicit); the penalty has
   // no gradient w.r.t. the covariate rows of W_1: zero those columns of the inter rows   :169-170
-  if (tail) {
+  if (gram) {
+  } else if (tail) {
     // slabs of g . W_1[:G]; one launch: slopes, f, D_1[inter] *= f, e_1, e_2 (in place), covariate zeroing
     int sk = 0;
     float *A1i = h->A[1] + (size_t)2 * B * h->ldh[1];
@@ -510,7 +569,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
       return AGX_OK;
     }
     Gemm g(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l], m.dims[l],
-           m.dims[l + 1], R);
+           m.dims[l + 1], l == 0 ? h->dw1_rows : R);
     g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID).sk(l == 0 && !fo && h->use_sk);
     // layer 1 in a captured iteration: rows [0,G) of W_1 (all rows with dw1_last) are updated in the
     // epilogue.  Safe: every reader of those rows (forward, input gradient, second-order product)
@@ -864,7 +923,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const bool fuse_big = seg < 0 && !a->split && B >= 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
   const bool fuse_gbig = fuse_big;
   const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
-                      agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], 3 * B, h->skws_floats);
+                      agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], dw1_rows(h, B), h->skws_floats);
   const bool fuse_g = (fuse || fuse_gbig) && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], B, h->skws_floats);
   agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
@@ -1205,7 +1264,7 @@ int big_grad_chunk(agx_cgan *h, hipStream_t st, bool gen, int r0, int r1, int B,
   const float *dl = gen ? h->Xbuf[0] + (size_t)B * h->ldx : h->D[1];
   const int ldd = gen ? h->ldx : h->ldh[1];
   float *out = (gen ? h->gg : h->dg) + m.w_off[l];
-  Gemm g(h, in + r0, ldin, 1, dl, ldd, 0, out + (size_t)r0 * m.ldw[l], m.ldw[l], r1 - r0, m.dims[l + 1], gen ? B : 3 * B);
+  Gemm g(h, in + r0, ldin, 1, dl, ldd, 0, out + (size_t)r0 * m.ldw[l], m.ldw[l], r1 - r0, m.dims[l + 1], gen ? B : dw1_rows(h, B));
   return g.id(gen ? AGX_K_GEN_DW_OUT : AGX_K_DISC_DW_IN).sk(true).run(st);
 }
 

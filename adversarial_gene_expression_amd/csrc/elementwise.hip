@@ -191,6 +191,32 @@ __global__ void __launch_bounds__(256) gp_finalize_kernel(const float *__restric
   for (int j = threadIdx.x; j < ncov; j += blockDim.x) xc[j] = 0.f;
 }
 
+// Gram form of the gradient penalty (cgan.hip critic_core): rows [0, H) of Xt <- the transposed gene rows of the
+// first kernel, Xt[h, g] = W[g, h]; covariate columns [G, G + ncov) of those rows <- 0 (the penalty has no gradient
+// w.r.t. the covariate rows of W_1).  64 x 64 tiles through LDS: both sides move whole 256-B row segments.
+__global__ void __launch_bounds__(256) wt_rows_kernel(const float *__restrict__ W, int ldw, int G, int H,
+                                                      float *__restrict__ Xt, int ldx, int ncov) {
+  __shared__ float t[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int g0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int g = g0 + r, hh = h0 + tx;
+    t[r][tx] = (g < G && hh < H) ? W[(size_t)g * ldw + hh] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int hh = h0 + r, g = g0 + tx;
+    if (hh < H && g < G) Xt[(size_t)hh * ldx + g] = t[tx][r];
+  }
+  if (blockIdx.x == 0)
+    for (int q = threadIdx.x; q < 64 * ncov; q += 256) {
+      const int hh = h0 + q / ncov;
+      if (hh < H) Xt[(size_t)hh * ldx + G + q % ncov] = 0.f;
+    }
+}
+
 // one block per row: s = ||g||_2 ; g *= coef*(s-1)/s
 __global__ void __launch_bounds__(256) gp_rownorm_scale_kernel(float *__restrict__ g, int ldg,
                                                                float *__restrict__ slopes, int G,
@@ -1096,6 +1122,15 @@ extern "C" int agx_critic_head(void *stream, const float *A, int32_t lda, const 
   if (R <= 0 || H <= 0) return AGX_OK;
   hipLaunchKernelGGL(critic_head_kernel, dim3(agx::cdiv(R, 4)), dim3(256), 0, agx::as_stream(stream),
                      A, lda, w, b, out, delta, ldd, R, H, n0, n1, c0, c1, c2, slope);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int agx::wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov) {
+  AGX_CHECK_ARG(W && Xt && G > 0 && H > 0 && ldw >= H && ldx >= G + ncov && ncov >= 0, "wt_rows: bad argument");
+  agx::ProfScope prof(agx::as_stream(stream), AGX_K_DISC_DX, 0.0, 8.0 * G * (double)H);
+  hipLaunchKernelGGL(wt_rows_kernel, dim3(agx::cdiv(G, 64), agx::cdiv(H, 64)), dim3(256), 0, agx::as_stream(stream), W, ldw, G, H,
+                     Xt, ldx, ncov);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

@@ -9,6 +9,7 @@
 //   mode 1 (tf_utils.py:168-170 and its derivative): s = sqrt(sum rowsq) (no epsilon);
 //           f = coef*(s-1)/s; D1 *= f; E1 = act'(A1) * f * sum_z slab_z  (in place over A1);
 //           E2 = act'(A2) * (E1 . W2)  (in place over A2); covariate columns of the rows zeroed
+//           (Gram form, TailArgs::gram: the slab is d_1 . W_g^T W_g and s^2 its dot product with d_1)
 //   mode 3 (generator step, tf_utils.py:255 through the two hidden layers): d2 = act'(h2) * sum_z slab_z (slabs of
 //           dX . W_out^T); d1 = act'(h1) * (d2 . W_2^T) - the split-K reduce and the hidden delta product in one launch
 //
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
   auto orow = [&](int k) { return interp ? r0 + k * R : p.row0 + r0 + k; };
 
   float f = 1.f;
-  if (MODE == 1) {
+  if (MODE == 1 && !p.gram) {
     // slopes from the per-slab partial sums of squares (same order as gp_finalize_kernel)
     float s = 0.f;
     if (i < nsl) {
@@ -163,6 +164,20 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
     }
     reinterpret_cast<float *>(&a1[c])[i] = e;
   } else {
+    float d1v = 0.f;
+    if (p.gram) {
+      // Gram form: v = (d_1 . W_g^T W_g)[row, c], so |g|^2 = |d_1 . W_g^T|^2 = sum_c v * d_1[row, c]   (:168-169)
+      if (i < nsl && c < p.H1) d1v = p.D1[(size_t)orow(i) * p.ldd1 + c];
+      const float s = wave_sum(v * d1v);
+      if (lane == 0) red[wave] = s;
+      __syncthreads();
+      const float sl = sqrtf((red[4 * i] + red[4 * i + 1]) + (red[4 * i + 2] + red[4 * i + 3]));
+      f = p.coef * (sl - 1.f) / sl;  // sl == 0 -> NaN propagates like the reference
+      if (lead && i < nsl && c == 0) {
+        p.slopes[srow(i)] = sl;
+        p.fscale[srow(i)] = f;
+      }
+    }
     float e = 0.f;
     if (i < nsl && c < p.H1) {
       const size_t o = (size_t)orow(i) * p.lda1 + c;
@@ -171,8 +186,13 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
       e = mk > 0.f ? x : x * p.slope;
       if (lead) {
         p.A1[o] = e;
-        float *d = p.D1 + (size_t)orow(i) * p.ldd1 + c;
-        *d = *d * f;
+        if (p.gram) {
+          p.gU[(size_t)srow(i) * p.ldg + c] = d1v;
+          p.gF[(size_t)srow(i) * p.ldg + c] = d1v * f;
+        } else {
+          float *d = p.D1 + (size_t)orow(i) * p.ldd1 + c;
+          *d = *d * f;
+        }
       }
     }
     if (lead && i < nsl && c < p.ncov) p.xcov[(size_t)srow(i) * p.ldx + c] = 0.f;
@@ -353,8 +373,9 @@ int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
     else if (a.nsplit == 2) hipLaunchKernelGGL((critic_tail_kernel<0, 2>), dim3(blocks, 2), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((critic_tail_kernel<0, 1>), dim3(blocks), dim3(1024), 0, st, a);
   } else {
-    AGX_CHECK_ARG(a.rowsq && a.slopes && a.fscale && a.D1 && a.ldd1 >= a.H1 && a.nslab >= 1 && a.rowsq_ld >= a.nslab &&
-                      a.ncov >= 0 && a.ncov <= 256 && (a.ncov == 0 || a.xcov),
+    AGX_CHECK_ARG(a.slopes && a.fscale && a.D1 && a.ldd1 >= a.H1 && a.ncov >= 0 && a.ncov <= 256 && (a.ncov == 0 || a.xcov) &&
+                      (a.gram ? (a.splitk == 1 && a.gU && a.gF && a.ldg >= a.H1)
+                              : (a.rowsq && a.nslab >= 1 && a.rowsq_ld >= a.nslab)),
                   "critic_tail: second-order arguments");
     agx::ProfScope prof(st, AGX_K_GP2_HID, 2.0 * a.m_slab * a.H1 * (double)a.H2,
                         4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));

@@ -34,7 +34,7 @@ def main(mode, size, opt_name, out_path):
     gopt, dopt = mk(), mk()
     T.set_seed(77)
     losses = []
-    for it in range(2):
+    for it in range(int(os.environ.get('DP_RUNNER_ITERS', '2'))):
         s = slice(it * B, (it + 1) * B)
         if mode in ('native', 'single'):
             d, g = T.train_iteration(x[s], cc[s], nc[s], gen, disc, gopt, dopt, nbc)
@@ -56,7 +56,7 @@ def main(mode, size, opt_name, out_path):
     sd = dopt.state_arrays(disc)
     slot = np.concatenate([a.reshape(-1) for a in sd['rms' if opt_name == 'rmsprop' else 'v']])
     np.savez(out_path, losses=np.array(losses), w=np.concatenate([w.reshape(-1) for w in gen.get_weights() + disc.get_weights()]),
-             slot=slot, iters=np.array([dopt.iterations, gopt.iterations]), offset=np.array([T._rng.offset]))
+             sizes=np.array([w.size for w in gen.get_weights() + disc.get_weights()]), slot=slot, iters=np.array([dopt.iterations, gopt.iterations]), offset=np.array([T._rng.offset]))
 
 
 if __name__ == '__main__':

@@ -5,7 +5,8 @@ and stream hand-over of the real path runs):
   * one piece (AGX_DP_CHUNKS=0): the same kernels in the same order as the Python-driven split = 2 sequence with
     the whole-buffer optimizer step -> weights, slots and losses BIT-identical;
   * four pieces: the large weight-gradient product runs as four row-chunk launches (another tiling, another
-    summation order) -> same losses (2e-4) and weights (99.9 % within 2e-6);
+    summation order) -> same losses (2e-4) and weights (99.9 % within 2e-6); at 512 rows these bounds hold after one
+    iteration and the flip-aware ones of test_gpu_fullsize.py after two (see _close);
   * both against the ordinary one-GPU captured iteration (fused optimizer) at the same bars;
   * RMSprop and Adam; a small shape and the GTEx shape at 512 rows (stream-K dW_1, 4 chunk launches).
 Multi-rank behaviour of the same exchange layout: tests/test_gpu_split8.py (8 emulated ranks, full size),
@@ -21,10 +22,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, mode, size, opt, chunks=0):
-    out = str(tmp_path / ('%s_%s_%s_%d.npz' % (mode, size, opt, chunks)))
+def _run(tmp_path, mode, size, opt, chunks=0, iters=2):
+    out = str(tmp_path / ('%s_%s_%s_%d_%d.npz' % (mode, size, opt, chunks, iters)))
     env = {k: v for k, v in os.environ.items() if not k.startswith('AGX_')}
     env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    env['DP_RUNNER_ITERS'] = str(iters)
     if mode == 'native':
         env.update(AGX_DP_FORCE='1', AGX_DP_CHUNKS=str(chunks))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_native_runner.py'), mode, size, opt, out], env=env,
@@ -33,11 +35,20 @@ def _run(tmp_path, mode, size, opt, chunks=0):
     return np.load(out)
 
 
-def _close(a, b, what):
+def _close(a, b, what, flips=False):
     assert np.all(np.isfinite(a['losses'])) and np.all(np.isfinite(b['losses']))
-    np.testing.assert_allclose(a['losses'], b['losses'], rtol=2e-4, atol=2e-4, err_msg=what)
     err = np.abs(a['w'] - b['w'])
-    assert np.quantile(err, 0.999) < 2e-6, (what, float(np.quantile(err, 0.999)), float(err.max()))
+    if flips:
+        # 512 rows, two iterations = six steps: two sequences that round differently meet ReLU-mask flips (the penalty
+        # is discontinuous in the masks; test_gpu_fullsize.py's header has the count and the 30x-per-step growth), so
+        # the flip-aware bounds of `gtex_b512_5steps` apply, tightened to what a one-flip history allows; the tight
+        # bounds are checked after ONE iteration, before any flip has had a step to grow
+        np.testing.assert_allclose(a['losses'], b['losses'], rtol=1e-3, atol=1e-3, err_msg=what)
+        assert np.quantile(err, 0.5) < 1e-7 and np.quantile(err, 0.99) < 2e-5 and np.quantile(err, 0.999) < 1e-4, \
+            (what, [float(np.quantile(err, q)) for q in (0.5, 0.99, 0.999)], float(err.max()))
+    else:
+        np.testing.assert_allclose(a['losses'], b['losses'], rtol=2e-4, atol=2e-4, err_msg=what)
+        assert np.quantile(err, 0.999) < 2e-6, (what, float(np.quantile(err, 0.999)), float(err.max()))
     assert list(a['iters']) == list(b['iters']) and int(a['offset'][0]) == int(b['offset'][0])
 
 
@@ -52,6 +63,11 @@ def test_overlapped_exchange_driver_with_one_rank(gpu, tmp_path, size, opt):
     np.testing.assert_array_equal(one['w'], emul['w'])
     np.testing.assert_array_equal(one['slot'], emul['slot'])
     assert np.abs(one['w'] - single['w']).max() > 0 or size == 'small'    # (another launch sequence than the fused one)
-    _close(four, one, 'four pieces vs one')
-    _close(four, single, 'four pieces vs the one-GPU iteration')
-    _close(one, single, 'one piece vs the one-GPU iteration')
+    big = size == 'gtex512'
+    _close(four, one, 'four pieces vs one', big)
+    _close(four, single, 'four pieces vs the one-GPU iteration', big)
+    _close(one, single, 'one piece vs the one-GPU iteration', big)
+    if big:   # one iteration (three steps): the tight bounds
+        one1, four1, single1 = _run(tmp_path, 'native', size, opt, 0, 1), _run(tmp_path, 'native', size, opt, 4, 1), _run(tmp_path, 'single', size, opt, 0, 1)
+        _close(four1, one1, 'four pieces vs one, one iteration')
+        _close(four1, single1, 'four pieces vs the one-GPU iteration, one iteration')

@@ -24,11 +24,11 @@ KNOBS = [
 ]
 
 
-def _run(tmp_path, name, env_extra):
+def _run(tmp_path, name, env_extra, shape='ecoli'):
     out = str(tmp_path / (name + '.npz'))
     env = {k: v for k, v in os.environ.items() if not k.startswith('AGX_')}
     env.update(env_extra)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'knob_runner.py'), out], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'knob_runner.py'), out, shape], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, (name, r.stderr[-2000:])
     return np.load(out)
@@ -51,3 +51,17 @@ def test_knob_sequence_computes_the_default_iteration(gpu, tmp_path, default_run
         # 12 RMSprop steps of 5e-4: a differently rounded gradient moves a weight by at most a few 1e-7
         # (see test_gpu_cgan.test_weights_after_steps for the sensitivity argument)
         assert np.quantile(err, 0.999) < 2e-6, (knob, tag, float(np.quantile(err, 0.999)), float(err.max()))
+
+
+def test_gram_form_computes_the_direct_form(gpu, tmp_path):
+    """Batches of at least 1.5 x the first hidden width take the Gram form of the gradient penalty (cgan.hip gram_ok:
+    |d_1 W_g^T|^2 = d_1 (W_g^T W_g) d_1^T, and so on): same algebra as the direct form (AGX_NO_GRAM), other rounding.  The
+    full-size 512-row cases of test_gpu_fullsize.py and test_gpu_split8.py compare the Gram form with the oracle."""
+    a = _run(tmp_path, 'gram', {}, 'gram')
+    b = _run(tmp_path, 'direct', {'AGX_NO_GRAM': '1'}, 'gram')
+    for tag in ('plain', 'aug'):
+        assert np.all(np.isfinite(a[tag + '_losses']))
+        np.testing.assert_allclose(a[tag + '_losses'], b[tag + '_losses'], rtol=2e-4, atol=2e-4)
+        err = np.abs(a[tag + '_w'] - b[tag + '_w'])
+        assert np.quantile(err, 0.999) < 2e-6, (tag, float(np.quantile(err, 0.999)), float(err.max()))
+        assert err.max() > 0, 'the two forms round differently: identical weights mean the knob selected nothing'

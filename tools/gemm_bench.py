@@ -18,6 +18,10 @@ def shapes_for(name):
     G, H, Dd = 18154, 256, 18161
     if name == 'square':
         return [('sq4096', 4096, 4096, 4096, 0, 0), ('sq2048', 2048, 2048, 2048, 0, 0), ('sq8192', 8192, 8192, 8192, 0, 0)]
+    if name == 'gram':   # the Gram form of the penalty's input-gradient terms
+        return [('gram W^T W    TN', H, H, G, 1, 0), ('gram WT WT^T  NT', H, H, G, 0, 1), ('T = d1 M      NN', 512, H, H, 0, 0),
+                ('S = d1^T f d1 TN', H, H, 512, 1, 0), ('dw_in K=1280  TN', Dd, H, 1280, 1, 0), ('dw_in K=1536  TN', Dd, H, 1536, 1, 0),
+                ('disc_dx       NT', 512, G, H, 0, 1), ('gp2_in        NN', 512, H, G, 0, 0)]
     B = 512 if name == 'gtex512' else 32
     return [
         ('gen_fwd_out   NN', B, G, H, 0, 0),
