@@ -267,10 +267,17 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True)
     tot = sum(v['ms'] for v in disc_prof.values())
     breakdown = {v['name']: round(v['ms'] / nprobe * 1e3, 1) for v in sorted(disc_prof.values(), key=lambda v: -v['ms'])}
     flops_iter = algorithmic_flops_per_iter(G, V, n_num, H, Z, B, nb_critic) if len(H) == 2 else None
+    # what the launches of one iteration actually multiply (sum of their own 2MNK tags): less than the SURVEY 8(d) count
+    # of the reference's algorithm, which whole_iter_* prices - the layer-1 forward of the interpolated rows comes from
+    # the real and fake rows' by linearity, and from 1.5 x the hidden width on the penalty's input-gradient terms go
+    # through the Gram matrix of W_1's gene rows (cgan.hip gram_ok)
+    flops_exec = sum(v['flops'] for v in disc_prof.values()) / nprobe
     res = dict(value=Bg * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roof, final_losses=final_losses,
                kernel_us_per_iter=breakdown, tagged_kernel_ms_per_iter=tot / nprobe,
                whole_iter_tflops=(flops_iter / (dt / steps) / 1e12) if flops_iter else None,
-               whole_iter_mfma_frac=(flops_iter / (dt / steps) / 1e12 / MFMA_F32_PEAK_TF) if flops_iter else None)
+               whole_iter_mfma_frac=(flops_iter / (dt / steps) / 1e12 / MFMA_F32_PEAK_TF) if flops_iter else None,
+               executed_tflops=flops_exec / (dt / steps) / 1e12, executed_mfma_frac=flops_exec / (dt / steps) / 1e12 / MFMA_F32_PEAK_TF,
+               flops_note='whole_iter_* = SURVEY 8(d) flops of the reference algorithm / measured time; executed_* = the 2MNK the launches really multiply')
     lib.agx_prof_reset()
     del gen, disc, x
     torch.cuda.empty_cache()
@@ -527,6 +534,7 @@ def main():
         'final_losses': res['final_losses'],
         'kernel_us_per_iter': res['kernel_us_per_iter'],
         'whole_iter_tflops': res['whole_iter_tflops'], 'whole_iter_mfma_frac': res['whole_iter_mfma_frac'],
+        'executed_tflops': res['executed_tflops'], 'executed_mfma_frac': res['executed_mfma_frac'], 'flops_note': res['flops_note'],
     }
     # 512 samples per GPU at every N: at N = 8 this IS BASELINE.json configs[2] (batch 4096 data parallel)
     want_secondary = a.secondary if a.secondary is not None else (a.batch != 512)
@@ -539,7 +547,8 @@ def main():
                                  'global_batch': 512 * world,
                                  'roofline': s['roofline'], 'kernel_us_per_iter': s['kernel_us_per_iter'],
                                  'whole_iter_tflops': s['whole_iter_tflops'],
-                                 'whole_iter_mfma_frac': s['whole_iter_mfma_frac'], 'final_losses': s['final_losses']}
+                                 'whole_iter_mfma_frac': s['whole_iter_mfma_frac'], 'executed_tflops': s['executed_tflops'],
+                                 'executed_mfma_frac': s['executed_mfma_frac'], 'final_losses': s['final_losses']}
         except Exception as e:                      # never lose the headline line to the secondary workload
             if world > 1:
                 raise                               # ranks must stay in step: a one-rank failure cannot be skipped
