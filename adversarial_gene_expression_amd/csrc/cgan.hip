@@ -53,6 +53,9 @@ struct agx_cgan {
   // d_1 and f*d_1 of the interpolated rows [Bm, ldh1] each
   float *gramM = nullptr, *gramT = nullptr, *gramU = nullptr, *gramF = nullptr;
   int dw1_rows = 0;                         // K of the critic's layer-1 weight-gradient product of the step being recorded
+  // factored generator step (gen_core): (W_out W_g)^T [H1, ldpt]; d_1^T h_L [H1, ldpt]; column sums of d_1 [H1]
+  float *genPT = nullptr, *genQ = nullptr, *genCs = nullptr;
+  int ldpt = 0;
   float *gin0 = nullptr;                    // [S*Bm, ldg0] generator layer-1 input [z | num | emb]
   float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [S*Bm, ldgh]
   float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas      [Bm, ldgh]
@@ -152,6 +155,10 @@ void carve(agx_cgan *h, float *base) {
   h->gramT = cv.take((int64_t)Bm * c.disc.dims[1]);
   h->gramU = cv.take((int64_t)Bm * h->ldh[1]);
   h->gramF = cv.take((int64_t)Bm * h->ldh[1]);
+  h->ldpt = r4(c.gen.dims[c.gen.n_layers - 1]);
+  h->genPT = cv.take((int64_t)c.disc.dims[1] * h->ldpt);
+  h->genQ = cv.take((int64_t)c.disc.dims[1] * h->ldpt);
+  h->genCs = cv.take(c.disc.dims[1]);
   h->gin0 = cv.take((int64_t)S * Bm * h->ldg0);
   const int Lg = c.gen.n_layers - 1;
   for (int l = 1; l <= Lg; ++l) {
@@ -203,6 +210,15 @@ void carve(agx_cgan *h, float *base) {
     need = std::max(need, agx_gemm_ws_floats(B, c.disc.dims[1], c.disc.dims[1]));
     need = std::max(need, agx_gemm_ws_floats(c.disc.dims[1], c.disc.dims[1], B));
     need = std::max(need, agx_gemm_ws_floats(c.disc.dims[0], c.disc.dims[1], 2 * B + c.disc.dims[1]));
+    // factored generator step: (W_out W_g)^T, d_1 P^T, d_1^T h_L, the output bias row, dW_out over H1 rows
+    {
+      const int HL = c.gen.dims[c.gen.n_layers - 1], H1 = c.disc.dims[1];
+      need = std::max(need, agx_gemm_ws_floats(H1, HL, c.x_dim));
+      need = std::max(need, agx_gemm_ws_floats(B, HL, H1));
+      need = std::max(need, agx_gemm_ws_floats(H1, HL, B));
+      need = std::max(need, agx_gemm_ws_floats(1, c.x_dim, H1));
+      need = std::max(need, agx_gemm_ws_floats(HL, c.x_dim, H1));
+    }
     for (int l = 0; l < c.gen.n_layers; ++l) {
       need = std::max(need, agx_gemm_ws_floats(B, c.gen.dims[l + 1], c.gen.dims[l]));
       need = std::max(need, agx_gemm_ws_floats(S * B, c.gen.dims[l + 1], c.gen.dims[l]));
@@ -369,6 +385,20 @@ bool gram_ok(const agx_cgan *h, int B) {
 }
 // rows of the critic's stacked layer-1 weight-gradient product
 int dw1_rows(const agx_cgan *h, int B) { return gram_ok(h, B) ? 2 * B + h->cfg.disc.dims[1] : 3 * B; }
+
+// Factored generator step, same idea (gen_core): the generator's output layer is linear (tf_utils.py:88), so with d_1
+// the critic's first-layer delta of the generated rows and h_L the generator's last hidden activations
+//   dX = d_1 W_g^T  is never formed:   dW_out = h_L^T dX = (d_1^T h_L)^T-as-TN . W_g^T        (K = H1 instead of B)
+//   db_out = colsum(dX) = colsum(d_1) . W_g^T;   dX W_out^T = d_1 . (W_out W_g)^T            (one H1 x HL x G product)
+// for batches of at least 1.5 x the wider of the two hidden widths.  AGX_NO_GRAM selects the direct form here too.
+bool gen_fact_ok(const agx_cgan *h, int B) {
+  static const bool off = getenv("AGX_NO_GRAM") != nullptr;
+  const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
+  const int HL = gm.dims[gm.n_layers - 1], H1 = m.dims[1];
+  return !off && !gm.bn && 2 * B >= 3 * std::max(HL, H1) && B <= h->Bm && h->ldx % 4 == 0;
+}
+// rows (K) of the generator's output-layer weight-gradient product
+int gen_dw_rows(const agx_cgan *h, int B) { return gen_fact_ok(h, B) ? h->cfg.disc.dims[1] : B; }
 
 agx::TailArgs tail_args(agx_cgan *h, int splitk, int m_slab) {
   const agx_mlp_desc_t &m = h->cfg.disc;
@@ -615,8 +645,19 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   int out_parts = 1;
   AGX_TRY(disc_layers_from(h, st, 0, B, B, 0, -invb, 0.f, 0.f, &out_parts));
   AGX_TRY(disc_backward_chain(h, st, B));
+  const bool fact = gen_fact_ok(h, B);
+  const int H1c = m.dims[1], HLg = gm.dims[Lg];
+  if (fact) {
+    // (see gen_fact_ok) W_g^T into the rows the input gradient would take; P^T = W_g^T W_out^T; Q = d_1^T h_L
+    AGX_TRY(agx::wt_rows(st, h->dp + m.w_off[0], m.ldw[0], G, H1c, dX, ldx, 0));
+    Gemm gp(h, dX, ldx, 0, h->gp + gm.w_off[Lg], gm.ldw[Lg], 1, h->genPT, h->ldpt, H1c, HLg, G);
+    AGX_TRY(gp.id(AGX_K_GEN_BWD_OUT).run(st));
+    AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 1, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], 0, h->genQ, h->ldpt,
+                 H1c, HLg, B).id(AGX_K_GEN_DW_HID).run(st));
+  } else {
   AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 0, h->dp + m.w_off[0], m.ldw[0], 1, dX, ldx, B, G, m.dims[1])
               .id(AGX_K_DISC_DX).run(st));
+  }
   // generator backward: delta chain and weight gradients on the one stream
   agx_small_grads_t j;
   memset(&j, 0, sizeof(j));
@@ -626,7 +667,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   int lddout = ldx;
   // small batches of the two-hidden-layer generator: split-K reduce + hidden delta product as one tail launch
   static const bool gen_tail_off = getenv("AGX_NO_GEN_TAIL") != nullptr;
-  const bool tail3 = !gen_tail_off && Lg == 2 && !gm.bn && B <= 64 && gm.dims[1] <= 256 && gm.dims[2] <= 256 &&
+  const bool tail3 = !gen_tail_off && !fact && Lg == 2 && !gm.bn && B <= 64 && gm.dims[1] <= 256 && gm.dims[2] <= 256 &&
                      gm.ldw[1] % 4 == 0;
   for (int l = Lg; l >= 0; --l) {
     const float *in = l == 0 ? h->gin0 + (size_t)gen_row0 * h->ldg0 : h->gh[l] + (size_t)gen_row0 * h->ldgh[l];
@@ -636,22 +677,33 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     const bool fused = fo && l == Lg;
     auto weight_grad = [&]() -> int {
       if (l == Lg && h->skip_big) return AGX_OK;   // (see critic_core)
-      Gemm g(h, in, ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l], gm.dims[l + 1], B);
+      const bool f = fact && l == Lg;   // dW_out = Q-as-TN . W_g^T over H1 rows
+      Gemm g(h, f ? h->genQ : in, f ? h->ldpt : ldin, 1, dout, lddout, 0, h->gg + gm.w_off[l], gm.ldw[l], gm.dims[l],
+             gm.dims[l + 1], f ? H1c : B);
       g.id(l == Lg ? AGX_K_GEN_DW_OUT : AGX_K_GEN_DW_HID);
       if (fused) g.opt(fo);
       return g.run(st);
     };
     if (l == Lg && h->skip_big) {
       // launched in row chunks by agx_cgan_dp_iteration
-    } else if (!fused && tn_fuse() && agx::tn_job_ok(gm.dims[l], gm.dims[l + 1], B)) {
+    } else if (!fused && tn_fuse() && agx::tn_job_ok(gm.dims[l], gm.dims[l + 1], (fact && l == Lg) ? H1c : B)) {
       // a few 32x32 tiles over K = B rows: rides the small-gradient launch at the end of the step
+      if (fact && l == Lg)   // (factored output layer: Q-as-TN . W_g^T over H1 rows)
+        tn.job[tn.n++] = agx::TnJobs::Job{h->genQ, dout, h->gg + gm.w_off[l], h->ldpt, lddout, gm.ldw[l], gm.dims[l],
+                                          gm.dims[l + 1], H1c};
+      else
       tn.job[tn.n++] = agx::TnJobs::Job{in, dout, h->gg + gm.w_off[l], ldin, lddout, gm.ldw[l], gm.dims[l],
                                         gm.dims[l + 1], B};
     } else if (!fused) {
       AGX_TRY(weight_grad());
     }
+    if (fact && l == Lg) {   // column sums of d_1 now, the bias row = those . W_g^T behind the small-gradient launch
+      j.cs_A[j.n_colsum] = h->D[1]; j.cs_lda[j.n_colsum] = h->ldh[1]; j.cs_r0[j.n_colsum] = 0; j.cs_r1[j.n_colsum] = B;
+      j.cs_H[j.n_colsum] = H1c; j.cs_out[j.n_colsum] = h->genCs;
+    } else {
     j.cs_A[j.n_colsum] = dout; j.cs_lda[j.n_colsum] = lddout; j.cs_r0[j.n_colsum] = 0; j.cs_r1[j.n_colsum] = B;
     j.cs_H[j.n_colsum] = gm.dims[l + 1]; j.cs_out[j.n_colsum] = h->gg + gm.b_off[l];
+    }
     ++j.n_colsum;
     if (l == Lg && tail3) {
       // the output layer's delta product leaves raw split-K slabs; one tail launch sums them, applies both ReLU masks
@@ -673,8 +725,10 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     } else if (l == Lg - 1 && tail3) {
       // (gd[l] written by the tail launch above)
     } else if (l > 0) {
-      Gemm g(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
-          gm.dims[l + 1]);
+      // (factored output layer: dX W_out^T = d_1 . P^T)
+      Gemm g = (fact && l == Lg) ? Gemm(h, h->D[1], h->ldh[1], 0, h->genPT, h->ldpt, 0, h->gd[l], h->ldgh[l], B, HLg, H1c)
+                                 : Gemm(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
+                                        gm.dims[l + 1]);
       g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
       AGX_TRY(g.run(st));
       if (gm.bn)   // gd[l] = dL/d(normalised value) -> dL/d(Dense output), gamma / beta gradients of hidden layer l - 1
@@ -697,11 +751,13 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   j.l_out_parts = out_parts; j.l_out_ld = 3 * h->Bm;
   j.l_inv_b = invb; j.l_gp_weight = 0.f; j.l_fake_sign = 1.f;
   AGX_TRY(agx::small_grads_run(st, &j, lc ? *lc : agx::LossCopy{nullptr, nullptr, 0}, &tn));
+  if (fact)   // db_out = colsum(d_1) . W_g^T
+    AGX_TRY(Gemm(h, h->genCs, H1c, 0, dX, ldx, 0, h->gg + gm.b_off[Lg], G, 1, G, H1c).id(AGX_K_GEN_DW_HID).run(st));
   if (fo && fo->rest_n > 0) {
     // output-layer product LAST: its launch also runs the flat update of every other generator
     // parameter, whose gradients the launches above have completed
-    Gemm g(h, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], 1, dX, ldx, 0, h->gg + gm.w_off[Lg], gm.ldw[Lg],
-           gm.dims[Lg], gm.dims[Lg + 1], B);
+    Gemm g(h, fact ? h->genQ : h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], fact ? h->ldpt : h->ldgh[Lg], 1, dX, ldx, 0,
+           h->gg + gm.w_off[Lg], gm.ldw[Lg], gm.dims[Lg], gm.dims[Lg + 1], fact ? H1c : B);
     AGX_TRY(g.id(AGX_K_GEN_DW_OUT).opt(fo).run(st));
   }
   return AGX_OK;
@@ -925,7 +981,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], dw1_rows(h, B), h->skws_floats);
   const bool fuse_g = (fuse || fuse_gbig) && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
-                      agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], B, h->skws_floats);
+                      agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], gen_dw_rows(h, B), h->skws_floats);
   agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
   agx::FusedOpt gfo{h->gp + ghole_lo, a->gen_rms + ghole_lo, gm0.dims[Lg0], a->lr_gen, a->rho, a->eps};
   // ... and the same launch updates the rest of the flat buffer:
@@ -1259,12 +1315,13 @@ namespace {
 int big_grad_chunk(agx_cgan *h, hipStream_t st, bool gen, int r0, int r1, int B, int gen_row0) {
   const agx_mlp_desc_t &m = gen ? h->cfg.gen : h->cfg.disc;
   const int l = gen ? m.n_layers - 1 : 0;
-  const float *in = gen ? h->gh[l] + (size_t)gen_row0 * h->ldgh[l] : h->Xbuf[0];
-  const int ldin = gen ? h->ldgh[l] : h->ldx;
+  const bool gfact = gen && gen_fact_ok(h, B);   // (gen_core: dW_out = Q-as-TN . W_g^T, W_g^T in the rows the input gradient would take)
+  const float *in = gen ? (gfact ? h->genQ : h->gh[l] + (size_t)gen_row0 * h->ldgh[l]) : h->Xbuf[0];
+  const int ldin = gen ? (gfact ? h->ldpt : h->ldgh[l]) : h->ldx;
   const float *dl = gen ? h->Xbuf[0] + (size_t)B * h->ldx : h->D[1];
   const int ldd = gen ? h->ldx : h->ldh[1];
   float *out = (gen ? h->gg : h->dg) + m.w_off[l];
-  Gemm g(h, in + r0, ldin, 1, dl, ldd, 0, out + (size_t)r0 * m.ldw[l], m.ldw[l], r1 - r0, m.dims[l + 1], gen ? B : dw1_rows(h, B));
+  Gemm g(h, in + r0, ldin, 1, dl, ldd, 0, out + (size_t)r0 * m.ldw[l], m.ldw[l], r1 - r0, m.dims[l + 1], gen ? gen_dw_rows(h, B) : dw1_rows(h, B));
   return g.id(gen ? AGX_K_GEN_DW_OUT : AGX_K_DISC_DW_IN).sk(true).run(st);
 }
 

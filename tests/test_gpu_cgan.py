@@ -35,7 +35,9 @@ def _check_grads(got, want, rtol=3e-5):
 
 CFGS = [dict(), dict(B=1, seed=2), dict(B=12, H=(16,), seed=3), dict(B=33, H=(24, 16), G=130, seed=4),
         dict(B=7, H=(12, 10, 8), V=(6, 8, 5, 11, 5, 3, 5), Z=10, seed=5),
-        dict(B=4, n_num=2, num_zero=False, seed=7), dict(B=32, G=300, H=(128, 128), V=(15, 3), Z=64, seed=8)]
+        dict(B=4, n_num=2, num_zero=False, seed=7), dict(B=32, G=300, H=(128, 128), V=(15, 3), Z=64, seed=8),
+        # batches of >= 1.5 x the hidden widths: Gram form of the penalty, factored generator step (cgan.hip gram_ok, gen_fact_ok)
+        dict(B=40, H=(16, 8), seed=9), dict(B=48, G=130, H=(24, 16), n_num=2, num_zero=False, seed=10)]
 
 
 @pytest.mark.parametrize('cfg', CFGS)
