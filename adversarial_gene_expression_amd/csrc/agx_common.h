@@ -88,10 +88,17 @@ struct TailArgs {
   // is the row's dot product of T with d_1 (rowsq unused); gU / gF (ld ldg) receive d_1 and f*d_1 for the
   // S = d_1^T diag(f) d_1 product and D1 is left alone
   int gram; float *gU, *gF; int ldg;
+  // mode 0 with interp_rows > 0, factored fake rows: the fake rows' layer-1 values come finished from ws2 [interp_rows, H1]
+  // (no slabs); ws then holds the real rows' slabs only (m_slab == interp_rows)
+  const float *ws2;
 };
 int critic_tail(void *stream, int mode, const TailArgs &a);
 // rows [0, H) of Xt <- W[0:G, 0:H]^T, their covariate columns [G, G + ncov) <- 0 (elementwise.hip; Gram form of the penalty)
 int wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov);
+// factored fake rows (cgan.hip `ff`): [W_out; b_out; unit rows of the covariate columns; 0] in front of the stacked input,
+// and the per-step [h | 1 | covariates] rows (elementwise.hip)
+int ff_stage(void *stream, const float *Wout, int ldw, const float *bout, int HL, int G, int ncov, float *Xhd, int ldx, int rows);
+int ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, float *Hx, int ldhx, int B);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused
 // epilogue, without split-K (then fused and unfused runs sum in the same order: bit-identical)
 bool gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats);

@@ -56,6 +56,15 @@ struct agx_cgan {
   // factored generator step (gen_core): (W_out W_g)^T [H1, ldpt]; d_1^T h_L [H1, ldpt]; column sums of d_1 [H1]
   float *genPT = nullptr, *genQ = nullptr, *genCs = nullptr;
   int ldpt = 0;
+  // factored fake rows (record_iteration `ff`): HD = hxp + H1 rows in FRONT of X and of D[1]:
+  //   X:    [W_out; b_out; unit rows of the covariate columns; 0-pad] (hx of hxp rows) then W_g^T (H1 rows)
+  //   D[1]: [Hx^T d_1(fake)] (hx of hxp rows)                                         then S     (H1 rows)
+  // ffHx = per-step [h | 1 | covariates] rows [Bm, ldhx]; ffP = the headroom rows through the critic's first layer
+  // [HD, ldh1] = [W_out W_g; b_out W_g; W_c; 0; W_g^T W_g]; ffAf = the fake rows' first-layer values [Bm, H1]
+  int HD = 0, hx = 0, hxp = 0, ldhx = 0;
+  float *ffHx = nullptr, *ffP = nullptr, *ffAf = nullptr;
+  bool ff = false;                          // set while an iteration with factored fake rows is recorded
+  int ff_row0 = 0;                          // row offset of the step's z batch in gh[]
   float *gin0 = nullptr;                    // [S*Bm, ldg0] generator layer-1 input [z | num | emb]
   float *gh[AGX_MAX_LAYERS + 1] = {};       // generator activations [S*Bm, ldgh]
   float *gd[AGX_MAX_LAYERS + 1] = {};       // generator deltas      [Bm, ldgh]
@@ -136,14 +145,21 @@ void carve(agx_cgan *h, float *base) {
   const agx_cgan_config_t &c = h->cfg;
   const int Bm = c.max_batch, S = h->S;
   Carver cv(base);
-  h->Xbuf[0] = cv.take((int64_t)3 * Bm * h->ldx);
-  h->Xbuf[1] = cv.take((int64_t)3 * Bm * h->ldx);
+  h->hx = c.gen.dims[c.gen.n_layers - 1] + 1 + h->ncov;
+  h->hxp = r4(h->hx);
+  h->ldhx = h->hxp;
+  h->HD = h->hxp + c.disc.dims[1];
+  for (int b = 0; b < 2; ++b) {
+    h->Xbuf[b] = cv.take((int64_t)(3 * Bm + h->HD) * h->ldx);
+    if (h->Xbuf[b]) h->Xbuf[b] += (size_t)h->HD * h->ldx;
+  }
   h->X = h->Xbuf[0];
   const int L = c.disc.n_layers - 1;
   for (int l = 1; l <= L; ++l) {
     h->ldh[l] = r4(c.disc.dims[l]);
     h->A[l] = cv.take((int64_t)3 * Bm * h->ldh[l]);
-    h->D[l] = cv.take((int64_t)3 * Bm * h->ldh[l]);
+    h->D[l] = cv.take((int64_t)(3 * Bm + (l == 1 ? h->HD : 0)) * h->ldh[l]);
+    if (l == 1 && h->D[l]) h->D[l] += (size_t)h->HD * h->ldh[l];
   }
   h->out = cv.take(4 * 3 * Bm);                      // up to 4 partial dot products per row (column-split tails)
   h->A1m = cv.take((int64_t)Bm * h->ldh[1]);         // interpolated rows' layer-1 activations: ReLU mask of tail mode 1
@@ -159,6 +175,9 @@ void carve(agx_cgan *h, float *base) {
   h->genPT = cv.take((int64_t)c.disc.dims[1] * h->ldpt);
   h->genQ = cv.take((int64_t)c.disc.dims[1] * h->ldpt);
   h->genCs = cv.take(c.disc.dims[1]);
+  h->ffHx = cv.take((int64_t)Bm * h->ldhx);
+  h->ffP = cv.take((int64_t)h->HD * h->ldh[1]);
+  h->ffAf = cv.take((int64_t)Bm * c.disc.dims[1]);
   h->gin0 = cv.take((int64_t)S * Bm * h->ldg0);
   const int Lg = c.gen.n_layers - 1;
   for (int l = 1; l <= Lg; ++l) {
@@ -218,6 +237,11 @@ void carve(agx_cgan *h, float *base) {
       need = std::max(need, agx_gemm_ws_floats(H1, HL, B));
       need = std::max(need, agx_gemm_ws_floats(1, c.x_dim, H1));
       need = std::max(need, agx_gemm_ws_floats(HL, c.x_dim, H1));
+      // factored fake rows: headroom rows through layer 1, Hx Px, Hx^T d_1, d_1 P^T, dW_1 over HD + B rows
+      need = std::max(need, agx_gemm_ws_floats(h->HD, H1, c.disc.dims[0]));
+      need = std::max(need, agx_gemm_ws_floats(B, H1, h->hx));
+      need = std::max(need, agx_gemm_ws_floats(h->hx, H1, B));
+      need = std::max(need, agx_gemm_ws_floats(c.disc.dims[0], H1, h->HD + B));
     }
     for (int l = 0; l < c.gen.n_layers; ++l) {
       need = std::max(need, agx_gemm_ws_floats(B, c.gen.dims[l + 1], c.gen.dims[l]));
@@ -295,7 +319,7 @@ int gen_input(agx_cgan *h, hipStream_t st, const float *z, const int32_t *cat, c
 // training (batch-norm generators only): batch statistics of the R rows (Keras training=True, tf_utils.py:244) and the
 // moving statistics updated; otherwise the moving statistics, folded into the Dense epilogue (training=False, :206)
 int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo, const agx::DualOut *dual = nullptr, int batch = 0,
-               bool training = false) {
+               bool training = false, bool hidden_only = false) {
   const agx_mlp_desc_t &m = h->cfg.gen;
   const float *in = h->gin0;
   int ldin = h->ldg0;
@@ -344,7 +368,7 @@ int gen_layers(agx_cgan *h, hipStream_t st, int R, float *out, int ldo, const ag
     ldin = h->ldgh[2];
     l0 = 2;
   }
-  for (int l = l0; l < m.n_layers; ++l) {
+  for (int l = l0; l < m.n_layers - (hidden_only ? 1 : 0); ++l) {
     const bool last = (l == m.n_layers - 1);
     float *o = last ? out : h->gh[l + 1];
     const int ldo_l = last ? ldo : h->ldgh[l + 1];
@@ -421,10 +445,15 @@ int tail_nsplit(int blocks) {
 }
 
 // *out_parts (optional): in = the caller can read the critic output as partial sums, out = how many parts it got
+// ws (optional): the slabs, if not the split-K scratch; ws2 (optional, interp_rows > 0): finished first-layer values of the
+// fake rows (factored fake rows: the slabs then hold the real rows only)
 int tail_forward(agx_cgan *h, hipStream_t st, int splitk, int m_slab, int interp_rows, const float *alpha, int n0,
-                 int n1, float c0, float c1, float c2, int *out_parts = nullptr) {
+                 int n1, float c0, float c1, float c2, int *out_parts = nullptr, const float *ws = nullptr,
+                 const float *ws2 = nullptr) {
   const agx_mlp_desc_t &m = h->cfg.disc;
   agx::TailArgs t = tail_args(h, splitk, m_slab);
+  if (ws) t.ws = ws;
+  t.ws2 = ws2;
   t.A1m = h->A1m;
   t.out_ld = 3 * h->Bm;
   t.nsplit = 1;
@@ -494,7 +523,28 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   float *Xi = h->X + (size_t)2 * B * ldx;
   const bool tail = tail_ok(h, B);
   int out_parts = 1;
-  if (tail) {
+  // factored fake rows (record_iteration `ff`; implies tail and gram): the fake rows x_f = h W_out + b_out (tf_utils.py:88,
+  // :206) are never formed.  The HD rows in front of X - [W_out; b_out; unit rows of the covariate columns; W_g^T] - go
+  // through the first layer ONCE per step: ffP = [W_out W_g; b_out W_g; W_c; 0; W_g^T W_g].  Its first hx rows turn the
+  // step's [h | 1 | covariates] rows into the fake rows' first-layer values, its last H1 rows are the Gram matrix.
+  const bool ff = h->ff;
+  const int HD = h->HD, hx = h->hx, hxp = h->hxp;
+  float *Xhd = h->X - (size_t)HD * ldx, *Dhd = h->D[1] - (size_t)HD * h->ldh[1];
+  if (ff) {
+    const int H1 = m.dims[1], ldh1 = h->ldh[1];
+    AGX_TRY(agx::wt_rows(st, h->dp + m.w_off[0], m.ldw[0], G, H1, Xhd + (size_t)hxp * ldx, ldx, h->ncov));
+    AGX_TRY(Gemm(h, Xhd, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->ffP, ldh1, HD, H1, m.dims[0]).id(AGX_K_DISC_DX).run(st));
+    const agx_mlp_desc_t &gm = h->cfg.gen;
+    const int Lg = gm.n_layers - 1;
+    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)h->ff_row0 * h->ldgh[Lg], h->ldgh[Lg], gm.dims[Lg], h->X, ldx, G, h->ncov,
+                       h->ffHx, h->ldhx, B));
+    AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, ldh1, 0, h->ffAf, H1, B, H1, hx).id(AGX_K_DISC_FWD_IN).run(st));
+    // the real rows' slabs LAST: they stay in the split-K scratch until the tail launch
+    int sk = 0;
+    AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], ldh1, B, H1, m.dims[0])
+                .id(AGX_K_DISC_FWD_IN).run_slabs(st, &sk));
+    AGX_TRY(tail_forward(h, st, sk, B, B, alpha, B, B, -invb, invb, 1.f, &out_parts, nullptr, h->ffAf));
+  } else if (tail) {
     // layer-1 slabs of [real; fake]; one launch finishes them (interpolated rows by linearity), runs
     // the second hidden layer and Dense(1) on the 3B rows and seeds the backward chain
     int sk = 0;
@@ -511,19 +561,23 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   AGX_TRY(disc_backward_chain(h, st, R));
   float *D1i = h->D[1] + (size_t)2 * B * h->ldh[1];
   const bool gram = tail && gram_ok(h, B);
-  h->dw1_rows = dw1_rows(h, B);
+  h->dw1_rows = ff ? HD + B : dw1_rows(h, B);
+  AGX_CHECK_ARG(!ff || gram, "critic_core: factored fake rows without the Gram form");
   if (gram) {
     // (see gram_ok) W_g^T into the inter rows of X; M; T = d_1 . M; one launch: slopes, f, e_1, e_2, copies of d_1
     // and f*d_1; S into the first H1 inter rows of D_1
     const int H1 = m.dims[1], ldh1 = h->ldh[1];
     const float *Wg = h->dp + m.w_off[0];
+    const float *M = ff ? h->ffP + (size_t)hxp * ldh1 : h->gramM;   // (ff: the last H1 rows of the headroom product)
+    if (!ff) {
     AGX_TRY(agx::wt_rows(st, Wg, m.ldw[0], G, H1, Xi, ldx, h->ncov));
     // (64x64 tiles over 32 K slices: 34.3 us against 40.8 for the plan's 128x128 tiles over 114 slices, whose partial
     //  sums are 30 MB; profiles/r03_gram_form.txt)
     Gemm gm(h, Wg, m.ldw[0], 1, Wg, m.ldw[0], 0, h->gramM, ldh1, H1, H1, G);
     if (H1 > 128 && G >= 4096) gm.force(1, 32);
     AGX_TRY(gm.id(AGX_K_DISC_DX).run(st));
-    AGX_TRY(Gemm(h, D1i, ldh1, 0, h->gramM, ldh1, 0, h->gramT, H1, B, H1, H1).id(AGX_K_GP2_IN).run(st));
+    }
+    AGX_TRY(Gemm(h, D1i, ldh1, 0, M, ldh1, 0, h->gramT, H1, B, H1, H1).id(AGX_K_GP2_IN).run(st));
     agx::TailArgs t = tail_args(h, 1, B);
     t.ws = h->gramT;
     t.row0 = 2 * B;
@@ -534,7 +588,11 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     t.nsplit = tail_nsplit((B + 3) / 4);
     t.gram = 1; t.gU = h->gramU; t.gF = h->gramF; t.ldg = ldh1;
     AGX_TRY(agx::critic_tail(st, 1, t));
-    AGX_TRY(Gemm(h, h->gramU, ldh1, 1, h->gramF, ldh1, 0, D1i, ldh1, H1, H1, B).id(AGX_K_GP2_IN).run(st));
+    // S in front of the real rows' deltas (ff) / over the first H1 inter rows
+    AGX_TRY(Gemm(h, h->gramU, ldh1, 1, h->gramF, ldh1, 0, ff ? Dhd + (size_t)hxp * ldh1 : D1i, ldh1, H1, H1, B)
+                .id(AGX_K_GP2_IN).run(st));
+    if (ff)   // the fake rows' term of dW_1: [W_out; b_out; unit rows]^T . (Hx^T d_1(fake))
+      AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 1, h->D[1] + (size_t)B * ldh1, ldh1, 0, Dhd, ldh1, hx, H1, B).id(AGX_K_GP2_IN).run(st));
   } else {
   // g = d_1 . W_1[:G]^T -> inter rows of X, with the per-slab row sums of squares as a side
   // output of the epilogue                                                      :168-169
@@ -591,14 +649,15 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   tn.n = 0;
   auto weight_grad = [&](int l) -> int {
     if (l == 0 && h->skip_big) return AGX_OK;   // launched in row chunks by agx_cgan_dp_iteration (big_grad_chunk)
-    const float *in = l == 0 ? h->X : h->A[l];
+    const float *in = l == 0 ? (ff ? Xhd : h->X) : h->A[l];
     const int ldin = l == 0 ? ldx : h->ldh[l];
     if (l > 0 && tn_fuse() && agx::tn_job_ok(m.dims[l], m.dims[l + 1], R)) {
       tn.job[tn.n++] = agx::TnJobs::Job{in, h->D[l + 1], h->dg + m.w_off[l], ldin, h->ldh[l + 1], m.ldw[l],
                                         m.dims[l], m.dims[l + 1], R};
       return AGX_OK;
     }
-    Gemm g(h, in, ldin, 1, h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l], m.dims[l],
+    // (ff: [headroom; real]^T . [Hx^T d_1(fake); 0; S; D_1(real)] over HD + B rows)
+    Gemm g(h, in, ldin, 1, (l == 0 && ff) ? Dhd : h->D[l + 1], h->ldh[l + 1], 0, h->dg + m.w_off[l], m.ldw[l], m.dims[l],
            m.dims[l + 1], l == 0 ? h->dw1_rows : R);
     g.id(l == 0 ? AGX_K_DISC_DW_IN : AGX_K_DISC_DW_HID).sk(l == 0 && !fo && h->use_sk);
     // layer 1 in a captured iteration: rows [0,G) of W_1 (all rows with dw1_last) are updated in the
@@ -640,18 +699,34 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
   const int Lg = gm.n_layers - 1, G = h->G, ldx = h->ldx;
   const float invb = 1.0f / (float)B_global;
-  float *dX = h->X + (size_t)B * ldx;
+  const bool fact = gen_fact_ok(h, B), ff = h->ff;
+  const int H1c = m.dims[1], HLg = gm.dims[Lg];
+  AGX_CHECK_ARG(!ff || fact, "gen_core: factored fake rows without the factored generator step");
+  // (ff: W_g^T sits in front of X, see critic_core)
+  float *dX = ff ? h->X - (size_t)H1c * ldx : h->X + (size_t)B * ldx;
   // critic forward (:250) + seed -1/B of d mean(-D)/d out; critic weights untouched   :255
   int out_parts = 1;
+  if (ff) {
+    // the generated rows are never formed: their first-layer values are [h | 1 | covariates] . [W_out W_g; b_out W_g; W_c]
+    float *Xhd = h->X - (size_t)h->HD * ldx;
+    AGX_TRY(agx::wt_rows(st, h->dp + m.w_off[0], m.ldw[0], G, H1c, dX, ldx, h->ncov));
+    AGX_TRY(Gemm(h, Xhd, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->ffP, h->ldh[1], h->hxp, H1c, m.dims[0])
+                .id(AGX_K_DISC_FWD_IN).run(st));
+    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], HLg, h->X, ldx, G, h->ncov, h->ffHx,
+                       h->ldhx, B));
+    AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, h->ldh[1], 0, h->ffAf, H1c, B, H1c, h->hx).id(AGX_K_DISC_FWD_IN).run(st));
+    AGX_TRY(tail_forward(h, st, 1, B, 0, nullptr, B, 0, -invb, 0.f, 0.f, &out_parts, h->ffAf));
+  } else {
   AGX_TRY(disc_layers_from(h, st, 0, B, B, 0, -invb, 0.f, 0.f, &out_parts));
+  }
   AGX_TRY(disc_backward_chain(h, st, B));
-  const bool fact = gen_fact_ok(h, B);
-  const int H1c = m.dims[1], HLg = gm.dims[Lg];
   if (fact) {
     // (see gen_fact_ok) W_g^T into the rows the input gradient would take; P^T = W_g^T W_out^T; Q = d_1^T h_L
+    if (!ff) {
     AGX_TRY(agx::wt_rows(st, h->dp + m.w_off[0], m.ldw[0], G, H1c, dX, ldx, 0));
     Gemm gp(h, dX, ldx, 0, h->gp + gm.w_off[Lg], gm.ldw[Lg], 1, h->genPT, h->ldpt, H1c, HLg, G);
     AGX_TRY(gp.id(AGX_K_GEN_BWD_OUT).run(st));
+    }
     AGX_TRY(Gemm(h, h->D[1], h->ldh[1], 1, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], 0, h->genQ, h->ldpt,
                  H1c, HLg, B).id(AGX_K_GEN_DW_HID).run(st));
   } else {
@@ -726,7 +801,9 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
       // (gd[l] written by the tail launch above)
     } else if (l > 0) {
       // (factored output layer: dX W_out^T = d_1 . P^T)
-      Gemm g = (fact && l == Lg) ? Gemm(h, h->D[1], h->ldh[1], 0, h->genPT, h->ldpt, 0, h->gd[l], h->ldgh[l], B, HLg, H1c)
+      // (ff: P = W_out W_g is the first HL rows of the headroom product)
+      Gemm g = (ff && l == Lg) ? Gemm(h, h->D[1], h->ldh[1], 0, h->ffP, h->ldh[1], 1, h->gd[l], h->ldgh[l], B, HLg, H1c)
+             : (fact && l == Lg) ? Gemm(h, h->D[1], h->ldh[1], 0, h->genPT, h->ldpt, 0, h->gd[l], h->ldgh[l], B, HLg, H1c)
                                  : Gemm(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
                                         gm.dims[l + 1]);
       g.mask(in, ldin).id(l == Lg ? AGX_K_GEN_BWD_OUT : AGX_K_GEN_BWD_HID);
@@ -978,8 +1055,11 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   // from 128 rows on both big products fuse as well (+0.7 % at 512 rows)
   const bool fuse_big = seg < 0 && !a->split && B >= 128 && !adam && !getenv("AGX_NO_FUSED_OPT");
   const bool fuse_gbig = fuse_big;
-  const bool fuse_d = (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
-                      agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], dw1_rows(h, B), h->skws_floats);
+  auto can_fuse_d = [&](int K) {
+    return (fuse || fuse_big) && dhole_hi % 4 == 0 && dhole_hi <= (dm.n_flat & ~(int64_t)3) &&
+           agx::gemm_can_fuse_opt(dm.dims[0], dm.dims[1], K, h->skws_floats);
+  };
+  bool fuse_d = can_fuse_d(dw1_rows(h, B));
   const bool fuse_g = (fuse || fuse_gbig) && ghole_hi % 4 == 0 && ghole_hi <= (gm0.n_flat & ~(int64_t)3) &&
                       agx::gemm_can_fuse_opt(gm0.dims[Lg0], gm0.dims[Lg0 + 1], gen_dw_rows(h, B), h->skws_floats);
   agx::FusedOpt dfo{h->dp + dhole_lo, a->disc_rms + dhole_lo, G, a->lr_disc, a->rho, a->eps};
@@ -989,6 +1069,14 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const bool rest = !getenv("AGX_NO_FUSED_REST");
   const int64_t dfull_hi = dm.w_off[0] + (int64_t)dm.dims[0] * dm.ldw[0];
   const bool rest_d = rest && dfull_hi % 4 == 0 && dfull_hi <= (dm.n_flat & ~(int64_t)3);
+  // Factored fake rows (critic_core / gen_core `ff`): the one-GPU RMSprop iteration without augmentation at batches that
+  // take the Gram form and the factored generator step.  The generator's output layer is linear, so neither the critic
+  // steps nor the generator step need the generated rows themselves: the generator runs its hidden layers only, and
+  // [W_out; b_out] rides in front of the stacked critic input (agx_cgan::HD).  AGX_NO_FF (or AGX_NO_GRAM): off.
+  static const bool ff_off = getenv("AGX_NO_FF") != nullptr;
+  const bool ff = !ff_off && seg < 0 && !a->split && nbc > 0 && !adam && gram_ok(h, B) && gen_fact_ok(h, B) && !a->aug_mask_disc &&
+                  !a->aug_mask_gen && rest && rest_d && fuse_g && can_fuse_d(h->HD + B);
+  if (ff) fuse_d = true;
   if (rest_d) {
     dfo.rows = dm.dims[0];
     dfo.rest_w = h->dp; dfo.rest_g = h->dg; dfo.rest_s1 = a->disc_rms;
@@ -1003,7 +1091,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   uint64_t sub = 0;
   // Step 0's stacked input without a copy launch (chained input assembly only): the generator's output product stores
   // its first B rows ALSO into the fake rows of buffer 0, the draws launch writes the covariate columns.
-  const bool chainx0 = seg < 0 && fuse_d && rest_d && chain_input(h, a);
+  const bool chainx0 = seg < 0 && !ff && fuse_d && rest_d && chain_input(h, a);
   // (small batches only: at 512 rows the second copy of the rows costs the product more than the launch it saves,
   //  186.4 k against 189.6 k samples/s)
   const bool fold0 = chainx0 && nbc > 0 && !a->aug_mask_disc && B <= 64 && 2 * nbc + 1 <= AGX_MAX_RNG_SEGS && !getenv("AGX_NO_DRAW_FUSE") &&
@@ -1073,9 +1161,10 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   *draws = (int64_t)sub;
   // chained input assembly (see chain_input): needs the critic product to carry the flat update; steps then
   // alternate between the two stacked-input buffers
-  const bool chainx = seg < 0 && fuse_d && rest_d && chain_input(h, a);
+  const bool chainx = seg < 0 && !ff && fuse_d && rest_d && chain_input(h, a);
   float *Xb[2] = {h->Xbuf[0], chainx ? h->Xbuf[1] : h->Xbuf[0]};
-  struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; h->use_sk = false; h->skip_big = false; } } restore{h};
+  struct Restore { agx_cgan *h; ~Restore() { h->X = h->Xbuf[0]; h->use_sk = false; h->skip_big = false; h->ff = false; } } restore{h};
+  h->ff = ff;
   h->use_sk = a->split >= 2;
   h->skip_big = a->split == 3;
   // fake rows of step k (k == nbc: the generator step's rows [0,B)) into buffer k&1; with_cov: also
@@ -1093,6 +1182,14 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     // iteration's last update): fake rows of step k = F[k*B : (k+1)*B]
     if (!draw_fuse) AGX_TRY(gen_input(h, st, h->zbuf, h->scat, h->snum, S * B, B));
     const agx::DualOut du{h->Xbuf[0] + (size_t)B * h->ldx, h->ldx, B};
+    if (ff) {
+      // hidden layers only; [W_out; b_out; unit rows; 0] in front of the stacked input, zero padding rows in front of D_1
+      AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx, nullptr, B, false, true));
+      AGX_TRY(agx::ff_stage(st, h->gp + gm0.w_off[Lg0], gm0.ldw[Lg0], h->gp + gm0.b_off[Lg0], gm0.dims[Lg0], G, h->ncov,
+                            h->Xbuf[0] - (size_t)h->HD * h->ldx, h->ldx, h->hxp));
+      if (h->hxp > h->hx)
+        AGX_HIP(hipMemsetAsync(h->D[1] - (size_t)(h->HD - h->hx) * h->ldh[1], 0, (size_t)(h->hxp - h->hx) * h->ldh[1] * sizeof(float), st));
+    } else
     AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx, fold0 ? &du : nullptr, B));
     // real rows were staged into buffer 0 rows [0,B) (agx_cgan_iter_stage) and stay there for all
     // critic steps (augmentation noise is a trace constant, :210); buffer 1 gets a copy
@@ -1102,6 +1199,9 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     h->X = Xb[k & 1];
     if (in_seg(k)) {
       // covariate columns of [real; fake] from the CURRENT (just updated) embedding tables
+      h->ff_row0 = k * B;
+      if (ff) AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));   // covariate columns of the real rows, current tables
+      else
       if (!chainx || (k == 0 && !fold0)) AGX_TRY(place_fake(k, st, true));
       agx::FusedOpt dk = dfo;
       if (chainx) {   // step k+1's rows (the generator step's rows [0,B) when k+1 == nbc) into the other buffer
@@ -1130,6 +1230,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   }
   h->X = Xb[nbc & 1];
   if (in_seg(nbc)) {
+    if (ff) AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));
+    else
     if (!chainx) AGX_TRY(place_fake(nbc, st, true));   // else: assembled by the last critic step's layer-1 product
     AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc,
                      fuse_g ? &gfo : nullptr, snap ? &lcopy : nullptr));

@@ -217,6 +217,35 @@ __global__ void __launch_bounds__(256) wt_rows_kernel(const float *__restrict__ 
     }
 }
 
+// Factored fake rows (cgan.hip record_iteration `ff`): the rows in front of the stacked critic input, one block per row.
+//   r < HL: [W_out[r, 0:G] | 0]   r == HL: [b_out | 0]   HL < r < HL + 1 + ncov: [0 | unit vector r - HL - 1]   above: 0
+__global__ void __launch_bounds__(256) ff_stage_kernel(const float *__restrict__ Wout, int ldw, const float *__restrict__ bout,
+                                                       int HL, int G, int ncov, float *__restrict__ Xhd, int ldx) {
+  const int r = blockIdx.y;
+  float *row = Xhd + (size_t)r * ldx;
+  const float *src = r < HL ? Wout + (size_t)r * ldw : (r == HL ? bout : nullptr);
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < G + ncov; c += gridDim.x * 256) {
+    float v = 0.f;
+    if (c < G) v = src ? src[c] : 0.f;
+    else v = (r > HL && c - G == r - HL - 1) ? 1.f : 0.f;
+    row[c] = v;
+  }
+}
+
+// Hx[i] = [h[i, 0:HL] | 1 | X[i, G:G+ncov] | 0 ...] (width ldhx): the generator's last hidden activations of the step's z
+// batch, the constant of the output bias and the rows' covariate columns
+__global__ void __launch_bounds__(256) ff_hx_kernel(const float *__restrict__ hrows, int ldh, int HL, const float *__restrict__ X,
+                                                    int ldx, int G, int ncov, float *__restrict__ Hx, int ldhx, int B) {
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < ldhx; c += 256) {
+    float v = 0.f;
+    if (c < HL) v = hrows[(size_t)i * ldh + c];
+    else if (c == HL) v = 1.f;
+    else if (c < HL + 1 + ncov) v = X[(size_t)i * ldx + G + (c - HL - 1)];
+    Hx[(size_t)i * ldhx + c] = v;
+  }
+}
+
 // one block per row: s = ||g||_2 ; g *= coef*(s-1)/s
 __global__ void __launch_bounds__(256) gp_rownorm_scale_kernel(float *__restrict__ g, int ldg,
                                                                float *__restrict__ slopes, int G,
@@ -1131,6 +1160,24 @@ int agx::wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt,
   agx::ProfScope prof(agx::as_stream(stream), AGX_K_DISC_DX, 0.0, 8.0 * G * (double)H);
   hipLaunchKernelGGL(wt_rows_kernel, dim3(agx::cdiv(G, 64), agx::cdiv(H, 64)), dim3(256), 0, agx::as_stream(stream), W, ldw, G, H,
                      Xt, ldx, ncov);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int agx::ff_stage(void *stream, const float *Wout, int ldw, const float *bout, int HL, int G, int ncov, float *Xhd, int ldx,
+                  int rows) {
+  AGX_CHECK_ARG(Wout && bout && Xhd && HL > 0 && G > 0 && ncov >= 0 && ldw >= G && ldx >= G + ncov && rows >= HL + 1 + ncov,
+                "ff_stage: bad argument");
+  hipLaunchKernelGGL(ff_stage_kernel, dim3(std::min(agx::cdiv(G + ncov, 256), 16), rows), dim3(256), 0, agx::as_stream(stream),
+                     Wout, ldw, bout, HL, G, ncov, Xhd, ldx);
+  AGX_LAUNCH_CHECK();
+  return AGX_OK;
+}
+
+int agx::ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, float *Hx, int ldhx,
+               int B) {
+  AGX_CHECK_ARG(hrows && X && Hx && B > 0 && ldh >= HL && ldhx >= HL + 1 + ncov, "ff_hx: bad argument");
+  hipLaunchKernelGGL(ff_hx_kernel, dim3(B), dim3(256), 0, agx::as_stream(stream), hrows, ldh, HL, X, ldx, G, ncov, Hx, ldhx, B);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

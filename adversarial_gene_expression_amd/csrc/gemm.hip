@@ -1058,7 +1058,9 @@ gemm_kernel(const KParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float q = half_wave_sum_at31(v[r] * v[r]);
-              if (l31 == 31 && rows[r] < p.M)   // v is 0 outside the matrix; lane 31's column names the slab
+              // v is 0 outside the matrix; lane 31's column names the slab.  A 32-column block that lies wholly
+              // beyond N (N mod 64 in 1..32 under a 64-wide tile) has no slab: its index is the NEXT row's slab 0
+              if (l31 == 31 && rows[r] < p.M && (col & ~31) < p.N)
                 p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
             }
           }
@@ -1387,7 +1389,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const KParams p) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const float sq = half_wave_sum_at31(v[q] * v[q]);
-          if (cc == 31 && rows[q] < p.M) p.rowsq[(size_t)rows[q] * p.rowsq_ld + (col >> 5)] = sq;
+          if (cc == 31 && rows[q] < p.M && (col & ~31) < p.N) p.rowsq[(size_t)rows[q] * p.rowsq_ld + (col >> 5)] = sq;
         }
       }
     }
@@ -1506,7 +1508,7 @@ __global__ void __launch_bounds__(64) gemm_wave_kernel(const KParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float q = half_wave_sum_at31(v[r] * v[r]);
-            if (i == 31 && rows[r] < p.M) p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
+            if (i == 31 && rows[r] < p.M && (col & ~31) < p.N) p.rowsq[(size_t)rows[r] * p.rowsq_ld + (col >> 5)] = q;
           }
         }
       }

@@ -101,6 +101,8 @@ __global__ void __launch_bounds__(1024) critic_tail_kernel(const agx::TailArgs p
       }
       for (; k < p.K_in; ++k) v = fmaf(xr[k], w[(size_t)k * p.ldw1], v);
     }
+  } else if (MODE == 0 && interp && p.ws2 && i == 1) {
+    if (c < p.H1) v = p.ws2[(size_t)r0 * p.H1 + c];   // factored fake row: finished value, no slabs
   } else if (i < nsl && c < p.H1) {
     const size_t stride = (size_t)p.H1;   // slabs [row][z][H1]: a row's partials are contiguous
     const float *s0 = p.ws + (size_t)srow(i) * p.splitk * p.H1 + c;
@@ -364,7 +366,7 @@ int agx::critic_tail(void *stream, int mode, const agx::TailArgs &a_in) {
     else hipLaunchKernelGGL((critic_tail_kernel<3, 1>), dim3(blocks), dim3(1024), 0, st, a);
   } else if (mode == 0) {
     AGX_CHECK_ARG(a.b1 && a.b2 && a.w3 && a.b3 && a.D2 && a.out && a.ldd2 >= a.H2 &&
-                      (a.interp_rows == 0 || (a.alpha && a.m_slab == 2 * a.interp_rows)),
+                      (a.interp_rows == 0 || (a.alpha && a.m_slab == (a.ws2 ? 1 : 2) * a.interp_rows)),
                   "critic_tail: forward arguments");
     agx::ProfScope prof(st, AGX_K_DISC_FWD_HID, 2.0 * (a.interp_rows ? 3 * a.interp_rows : a.m_slab) * a.H1 * (double)a.H2,
                         4.0 * ((double)a.splitk * a.m_slab * a.H1 + (double)a.H1 * a.H2));

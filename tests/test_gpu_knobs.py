@@ -53,15 +53,20 @@ def test_knob_sequence_computes_the_default_iteration(gpu, tmp_path, default_run
         assert np.quantile(err, 0.999) < 2e-6, (knob, tag, float(np.quantile(err, 0.999)), float(err.max()))
 
 
-def test_gram_form_computes_the_direct_form(gpu, tmp_path):
+@pytest.mark.parametrize('knob', ['AGX_NO_GRAM', 'AGX_NO_FF'])
+def test_gram_form_computes_the_direct_form(gpu, tmp_path, knob):
     """Batches of at least 1.5 x the first hidden width take the Gram form of the gradient penalty (cgan.hip gram_ok:
     |d_1 W_g^T|^2 = d_1 (W_g^T W_g) d_1^T, and so on): same algebra as the direct form (AGX_NO_GRAM), other rounding.  The
-    full-size 512-row cases of test_gpu_fullsize.py and test_gpu_split8.py compare the Gram form with the oracle."""
+    full-size 512-row cases of test_gpu_fullsize.py and test_gpu_split8.py compare the Gram form with the oracle.
+    On top of it the one-GPU iteration without augmentation never forms the generated rows (record_iteration `ff`:
+    x_f = h W_out + b_out enters every product through W_out W_g); AGX_NO_FF keeps the Gram form and the factored generator
+    step but materialises the rows, AGX_NO_GRAM selects the direct form of everything."""
     a = _run(tmp_path, 'gram', {}, 'gram')
-    b = _run(tmp_path, 'direct', {'AGX_NO_GRAM': '1'}, 'gram')
+    b = _run(tmp_path, 'direct', {knob: '1'}, 'gram')
     for tag in ('plain', 'aug'):
         assert np.all(np.isfinite(a[tag + '_losses']))
         np.testing.assert_allclose(a[tag + '_losses'], b[tag + '_losses'], rtol=2e-4, atol=2e-4)
         err = np.abs(a[tag + '_w'] - b[tag + '_w'])
         assert np.quantile(err, 0.999) < 2e-6, (tag, float(np.quantile(err, 0.999)), float(err.max()))
-        assert err.max() > 0, 'the two forms round differently: identical weights mean the knob selected nothing'
+        if tag == 'plain' or knob == 'AGX_NO_GRAM':   # (with augmentation the generated rows are formed anyway)
+            assert err.max() > 0, 'the two forms round differently: identical weights mean the knob selected nothing'
