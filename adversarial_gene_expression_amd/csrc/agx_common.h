@@ -94,11 +94,14 @@ struct TailArgs {
 };
 int critic_tail(void *stream, int mode, const TailArgs &a);
 // rows [0, H) of Xt <- W[0:G, 0:H]^T, their covariate columns [G, G + ncov) <- 0 (elementwise.hip; Gram form of the penalty)
-int wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov);
+int wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov, const float *bvec = nullptr,
+            float *bpart = nullptr);
 // factored fake rows (cgan.hip `ff`): [W_out; b_out; unit rows of the covariate columns; 0] in front of the stacked input,
 // and the per-step [h | 1 | covariates] rows (elementwise.hip)
-int ff_stage(void *stream, const float *Wout, int ldw, const float *bout, int HL, int G, int ncov, float *Xhd, int ldx, int rows);
-int ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, float *Hx, int ldhx, int B);
+int ff_stage(void *stream, const float *Wout, int ldw, const float *bout, int HL, int G, int ncov, int he, float *Xhd, int ldx,
+             int rows);
+int ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, int he, float *Hx, int ldhx,
+          int B, const float *bpart, int ntile, const float *W1, int ldw, int H1, float *P, int ldp);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused
 // epilogue, without split-K (then fused and unfused runs sum in the same order: bit-identical)
 bool gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats);

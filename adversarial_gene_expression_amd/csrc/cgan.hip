@@ -57,12 +57,14 @@ struct agx_cgan {
   float *genPT = nullptr, *genQ = nullptr, *genCs = nullptr;
   int ldpt = 0;
   // factored fake rows (record_iteration `ff`): HD = hxp + H1 rows in FRONT of X and of D[1]:
-  //   X:    [W_out; b_out; unit rows of the covariate columns; 0-pad] (hx of hxp rows) then W_g^T (H1 rows)
-  //   D[1]: [Hx^T d_1(fake)] (hx of hxp rows)                                         then S     (H1 rows)
-  // ffHx = per-step [h | 1 | covariates] rows [Bm, ldhx]; ffP = the headroom rows through the critic's first layer
-  // [HD, ldh1] = [W_out W_g; b_out W_g; W_c; 0; W_g^T W_g]; ffAf = the fake rows' first-layer values [Bm, H1]
-  int HD = 0, hx = 0, hxp = 0, ldhx = 0;
-  float *ffHx = nullptr, *ffP = nullptr, *ffAf = nullptr;
+  //   X:    [b_out; unit rows of the covariate columns; 0 (he rows) | W_out (HL rows) | 0-pad to hxp] then W_g^T (H1 rows)
+  //   D[1]: [Hx^T d_1(fake)] (hx = he + HL of hxp rows)                                              then S     (H1 rows)
+  // ffHx = per-step [1 | covariates | 0 | h] rows [Bm, ldhx]; ffP [HD + Bm, ldp = H1] = the first-layer image of those
+  // rows and of the real rows: [b_out W_g; W_c; 0 | W_out W_g | 0 | W_g^T W_g | real rows' pre-activations] - rows he..
+  // are ONE product (for GTEx at 512 rows: 256 + 256 + 512 = 1024 rows), the first he rows need none (ff_hx_kernel);
+  // ffAf = the fake rows' first-layer values [Bm, H1]; ffBp = per-gene-tile partials of b_out . W_g (wt_rows_kernel)
+  int HD = 0, he = 0, hx = 0, hxp = 0, ldhx = 0, ldp = 0, ntile = 0;
+  float *ffHx = nullptr, *ffP = nullptr, *ffAf = nullptr, *ffBp = nullptr;
   bool ff = false;                          // set while an iteration with factored fake rows is recorded
   int ff_row0 = 0;                          // row offset of the step's z batch in gh[]
   float *gin0 = nullptr;                    // [S*Bm, ldg0] generator layer-1 input [z | num | emb]
@@ -145,8 +147,11 @@ void carve(agx_cgan *h, float *base) {
   const agx_cgan_config_t &c = h->cfg;
   const int Bm = c.max_batch, S = h->S;
   Carver cv(base);
-  h->hx = c.gen.dims[c.gen.n_layers - 1] + 1 + h->ncov;
+  h->he = r4(1 + h->ncov);
+  h->hx = h->he + c.gen.dims[c.gen.n_layers - 1];
   h->hxp = r4(h->hx);
+  h->ldp = c.disc.dims[1];
+  h->ntile = (c.x_dim + 63) / 64;
   h->ldhx = h->hxp;
   h->HD = h->hxp + c.disc.dims[1];
   for (int b = 0; b < 2; ++b) {
@@ -176,8 +181,9 @@ void carve(agx_cgan *h, float *base) {
   h->genQ = cv.take((int64_t)c.disc.dims[1] * h->ldpt);
   h->genCs = cv.take(c.disc.dims[1]);
   h->ffHx = cv.take((int64_t)Bm * h->ldhx);
-  h->ffP = cv.take((int64_t)h->HD * h->ldh[1]);
+  h->ffP = cv.take((int64_t)(h->HD + Bm) * h->ldp);
   h->ffAf = cv.take((int64_t)Bm * c.disc.dims[1]);
+  h->ffBp = cv.take((int64_t)h->ntile * c.disc.dims[1]);
   h->gin0 = cv.take((int64_t)S * Bm * h->ldg0);
   const int Lg = c.gen.n_layers - 1;
   for (int l = 1; l <= Lg; ++l) {
@@ -238,7 +244,7 @@ void carve(agx_cgan *h, float *base) {
       need = std::max(need, agx_gemm_ws_floats(1, c.x_dim, H1));
       need = std::max(need, agx_gemm_ws_floats(HL, c.x_dim, H1));
       // factored fake rows: headroom rows through layer 1, Hx Px, Hx^T d_1, d_1 P^T, dW_1 over HD + B rows
-      need = std::max(need, agx_gemm_ws_floats(h->HD, H1, c.disc.dims[0]));
+      need = std::max(need, agx_gemm_ws_floats(h->HD + B, H1, c.disc.dims[0]));
       need = std::max(need, agx_gemm_ws_floats(B, H1, h->hx));
       need = std::max(need, agx_gemm_ws_floats(h->hx, H1, B));
       need = std::max(need, agx_gemm_ws_floats(c.disc.dims[0], H1, h->HD + B));
@@ -528,22 +534,23 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   // through the first layer ONCE per step: ffP = [W_out W_g; b_out W_g; W_c; 0; W_g^T W_g].  Its first hx rows turn the
   // step's [h | 1 | covariates] rows into the fake rows' first-layer values, its last H1 rows are the Gram matrix.
   const bool ff = h->ff;
-  const int HD = h->HD, hx = h->hx, hxp = h->hxp;
+  const int HD = h->HD, he = h->he, hx = h->hx, hxp = h->hxp, ldp = h->ldp;
   float *Xhd = h->X - (size_t)HD * ldx, *Dhd = h->D[1] - (size_t)HD * h->ldh[1];
   if (ff) {
-    const int H1 = m.dims[1], ldh1 = h->ldh[1];
-    AGX_TRY(agx::wt_rows(st, h->dp + m.w_off[0], m.ldw[0], G, H1, Xhd + (size_t)hxp * ldx, ldx, h->ncov));
-    AGX_TRY(Gemm(h, Xhd, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->ffP, ldh1, HD, H1, m.dims[0]).id(AGX_K_DISC_DX).run(st));
+    const int H1 = m.dims[1];
     const agx_mlp_desc_t &gm = h->cfg.gen;
     const int Lg = gm.n_layers - 1;
-    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)h->ff_row0 * h->ldgh[Lg], h->ldgh[Lg], gm.dims[Lg], h->X, ldx, G, h->ncov,
-                       h->ffHx, h->ldhx, B));
-    AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, ldh1, 0, h->ffAf, H1, B, H1, hx).id(AGX_K_DISC_FWD_IN).run(st));
-    // the real rows' slabs LAST: they stay in the split-K scratch until the tail launch
-    int sk = 0;
-    AGX_TRY(Gemm(h, h->X, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->A[1], ldh1, B, H1, m.dims[0])
-                .id(AGX_K_DISC_FWD_IN).run_slabs(st, &sk));
-    AGX_TRY(tail_forward(h, st, sk, B, B, alpha, B, B, -invb, invb, 1.f, &out_parts, nullptr, h->ffAf));
+    const float *W1 = h->dp + m.w_off[0];
+    // W_g^T behind the W_out rows (and the tiles' shares of b_out . W_g); then ONE product: rows he.. of the headroom
+    // and the real rows through the first layer (GTEx at 512 rows: 1024 rows, the shape of the old [real; fake] forward)
+    AGX_TRY(agx::wt_rows(st, W1, m.ldw[0], G, H1, Xhd + (size_t)hxp * ldx, ldx, h->ncov, h->gp + gm.b_off[Lg], h->ffBp));
+    AGX_TRY(Gemm(h, Xhd + (size_t)he * ldx, ldx, 0, W1, m.ldw[0], 0, h->ffP + (size_t)he * ldp, ldp, HD - he + B, H1, m.dims[0])
+                .id(AGX_K_DISC_FWD_IN).run(st));
+    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)h->ff_row0 * h->ldgh[Lg], h->ldgh[Lg], gm.dims[Lg], h->X, ldx, G, h->ncov, he,
+                       h->ffHx, h->ldhx, B, h->ffBp, h->ntile, W1, m.ldw[0], H1, h->ffP, ldp));
+    AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, ldp, 0, h->ffAf, H1, B, H1, hx).id(AGX_K_DISC_FWD_HID).run(st));
+    // the tail takes the real rows' finished values as ONE slab (ffP is compact: ldp = H1) and the fake rows' from ffAf
+    AGX_TRY(tail_forward(h, st, 1, B, B, alpha, B, B, -invb, invb, 1.f, &out_parts, h->ffP + (size_t)HD * ldp, h->ffAf));
   } else if (tail) {
     // layer-1 slabs of [real; fake]; one launch finishes them (interpolated rows by linearity), runs
     // the second hidden layer and Dense(1) on the 3B rows and seeds the backward chain
@@ -568,7 +575,8 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     // and f*d_1; S into the first H1 inter rows of D_1
     const int H1 = m.dims[1], ldh1 = h->ldh[1];
     const float *Wg = h->dp + m.w_off[0];
-    const float *M = ff ? h->ffP + (size_t)hxp * ldh1 : h->gramM;   // (ff: the last H1 rows of the headroom product)
+    const float *M = ff ? h->ffP + (size_t)hxp * ldp : h->gramM;   // (ff: H1 rows of the one first-layer product)
+    const int ldM = ff ? ldp : ldh1;
     if (!ff) {
     AGX_TRY(agx::wt_rows(st, Wg, m.ldw[0], G, H1, Xi, ldx, h->ncov));
     // (64x64 tiles over 32 K slices: 34.3 us against 40.8 for the plan's 128x128 tiles over 114 slices, whose partial
@@ -577,7 +585,7 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     if (H1 > 128 && G >= 4096) gm.force(1, 32);
     AGX_TRY(gm.id(AGX_K_DISC_DX).run(st));
     }
-    AGX_TRY(Gemm(h, D1i, ldh1, 0, M, ldh1, 0, h->gramT, H1, B, H1, H1).id(AGX_K_GP2_IN).run(st));
+    AGX_TRY(Gemm(h, D1i, ldh1, 0, M, ldM, 0, h->gramT, H1, B, H1, H1).id(AGX_K_GP2_IN).run(st));
     agx::TailArgs t = tail_args(h, 1, B);
     t.ws = h->gramT;
     t.row0 = 2 * B;
@@ -709,12 +717,13 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
   if (ff) {
     // the generated rows are never formed: their first-layer values are [h | 1 | covariates] . [W_out W_g; b_out W_g; W_c]
     float *Xhd = h->X - (size_t)h->HD * ldx;
-    AGX_TRY(agx::wt_rows(st, h->dp + m.w_off[0], m.ldw[0], G, H1c, dX, ldx, h->ncov));
-    AGX_TRY(Gemm(h, Xhd, ldx, 0, h->dp + m.w_off[0], m.ldw[0], 0, h->ffP, h->ldh[1], h->hxp, H1c, m.dims[0])
-                .id(AGX_K_DISC_FWD_IN).run(st));
-    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], HLg, h->X, ldx, G, h->ncov, h->ffHx,
-                       h->ldhx, B));
-    AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, h->ldh[1], 0, h->ffAf, H1c, B, H1c, h->hx).id(AGX_K_DISC_FWD_IN).run(st));
+    const float *W1 = h->dp + m.w_off[0];
+    AGX_TRY(agx::wt_rows(st, W1, m.ldw[0], G, H1c, dX, ldx, h->ncov, h->gp + gm.b_off[Lg], h->ffBp));
+    AGX_TRY(Gemm(h, Xhd + (size_t)h->he * ldx, ldx, 0, W1, m.ldw[0], 0, h->ffP + (size_t)h->he * h->ldp, h->ldp, HLg, H1c,
+                 m.dims[0]).id(AGX_K_DISC_FWD_IN).run(st));
+    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], HLg, h->X, ldx, G, h->ncov, h->he, h->ffHx,
+                       h->ldhx, B, h->ffBp, h->ntile, W1, m.ldw[0], H1c, h->ffP, h->ldp));
+    AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, h->ldp, 0, h->ffAf, H1c, B, H1c, h->hx).id(AGX_K_DISC_FWD_HID).run(st));
     AGX_TRY(tail_forward(h, st, 1, B, 0, nullptr, B, 0, -invb, 0.f, 0.f, &out_parts, h->ffAf));
   } else {
   AGX_TRY(disc_layers_from(h, st, 0, B, B, 0, -invb, 0.f, 0.f, &out_parts));
@@ -802,7 +811,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     } else if (l > 0) {
       // (factored output layer: dX W_out^T = d_1 . P^T)
       // (ff: P = W_out W_g is the first HL rows of the headroom product)
-      Gemm g = (ff && l == Lg) ? Gemm(h, h->D[1], h->ldh[1], 0, h->ffP, h->ldh[1], 1, h->gd[l], h->ldgh[l], B, HLg, H1c)
+      Gemm g = (ff && l == Lg) ? Gemm(h, h->D[1], h->ldh[1], 0, h->ffP + (size_t)h->he * h->ldp, h->ldp, 1, h->gd[l], h->ldgh[l], B, HLg, H1c)
              : (fact && l == Lg) ? Gemm(h, h->D[1], h->ldh[1], 0, h->genPT, h->ldpt, 0, h->gd[l], h->ldgh[l], B, HLg, H1c)
                                  : Gemm(h, dout, lddout, 0, h->gp + gm.w_off[l], gm.ldw[l], 1, h->gd[l], h->ldgh[l], B, gm.dims[l],
                                         gm.dims[l + 1]);
@@ -1185,7 +1194,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     if (ff) {
       // hidden layers only; [W_out; b_out; unit rows; 0] in front of the stacked input, zero padding rows in front of D_1
       AGX_TRY(gen_layers(h, st, S * B, h->F, h->ldsx, nullptr, B, false, true));
-      AGX_TRY(agx::ff_stage(st, h->gp + gm0.w_off[Lg0], gm0.ldw[Lg0], h->gp + gm0.b_off[Lg0], gm0.dims[Lg0], G, h->ncov,
+      AGX_TRY(agx::ff_stage(st, h->gp + gm0.w_off[Lg0], gm0.ldw[Lg0], h->gp + gm0.b_off[Lg0], gm0.dims[Lg0], G, h->ncov, h->he,
                             h->Xbuf[0] - (size_t)h->HD * h->ldx, h->ldx, h->hxp));
       if (h->hxp > h->hx)
         AGX_HIP(hipMemsetAsync(h->D[1] - (size_t)(h->HD - h->hx) * h->ldh[1], 0, (size_t)(h->hxp - h->hx) * h->ldh[1] * sizeof(float), st));

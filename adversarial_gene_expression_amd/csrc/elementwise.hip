@@ -194,17 +194,26 @@ __global__ void __launch_bounds__(256) gp_finalize_kernel(const float *__restric
 // Gram form of the gradient penalty (cgan.hip critic_core): rows [0, H) of Xt <- the transposed gene rows of the
 // first kernel, Xt[h, g] = W[g, h]; covariate columns [G, G + ncov) of those rows <- 0 (the penalty has no gradient
 // w.r.t. the covariate rows of W_1).  64 x 64 tiles through LDS: both sides move whole 256-B row segments.
+// bvec (optional, [G]) / bpart [gridDim.x, H]: the tile's share of bvec . W[0:G, :] as a by-product of the pass
+// (row sums over the tile's 64 rows in a fixed order; ff_hx_kernel adds the tiles up in order: deterministic)
 __global__ void __launch_bounds__(256) wt_rows_kernel(const float *__restrict__ W, int ldw, int G, int H,
-                                                      float *__restrict__ Xt, int ldx, int ncov) {
+                                                      float *__restrict__ Xt, int ldx, int ncov,
+                                                      const float *__restrict__ bvec, float *__restrict__ bpart) {
   __shared__ float t[64][65];
+  __shared__ float bp[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int g0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+  float bs = 0.f;
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {
     const int g = g0 + r, hh = h0 + tx;
-    t[r][tx] = (g < G && hh < H) ? W[(size_t)g * ldw + hh] : 0.f;
+    const float w = (g < G && hh < H) ? W[(size_t)g * ldw + hh] : 0.f;
+    t[r][tx] = w;
+    if (bvec) bs += (g < G ? bvec[g] : 0.f) * w;
   }
+  if (bvec) bp[ty][tx] = bs;
   __syncthreads();
+  if (bvec && ty == 0 && h0 + tx < H) bpart[(size_t)blockIdx.x * H + h0 + tx] = (bp[0][tx] + bp[1][tx]) + (bp[2][tx] + bp[3][tx]);
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {
     const int hh = h0 + r, g = g0 + tx;
@@ -218,30 +227,61 @@ __global__ void __launch_bounds__(256) wt_rows_kernel(const float *__restrict__ 
 }
 
 // Factored fake rows (cgan.hip record_iteration `ff`): the rows in front of the stacked critic input, one block per row.
-//   r < HL: [W_out[r, 0:G] | 0]   r == HL: [b_out | 0]   HL < r < HL + 1 + ncov: [0 | unit vector r - HL - 1]   above: 0
+//   r == 0: [b_out | 0]   1 <= r <= ncov: [0 | unit vector r - 1]   ncov < r < he: 0   he <= r < he + HL: [W_out[r - he] | 0]
+//   above: 0   (he = 1 + ncov rounded up to a multiple of 4: the W_out rows start a 16-byte-aligned block of rows)
 __global__ void __launch_bounds__(256) ff_stage_kernel(const float *__restrict__ Wout, int ldw, const float *__restrict__ bout,
-                                                       int HL, int G, int ncov, float *__restrict__ Xhd, int ldx) {
+                                                       int HL, int G, int ncov, int he, float *__restrict__ Xhd, int ldx) {
   const int r = blockIdx.y;
   float *row = Xhd + (size_t)r * ldx;
-  const float *src = r < HL ? Wout + (size_t)r * ldw : (r == HL ? bout : nullptr);
+  const float *src = r == 0 ? bout : ((r >= he && r < he + HL) ? Wout + (size_t)(r - he) * ldw : nullptr);
   for (int c = blockIdx.x * 256 + threadIdx.x; c < G + ncov; c += gridDim.x * 256) {
     float v = 0.f;
     if (c < G) v = src ? src[c] : 0.f;
-    else v = (r > HL && c - G == r - HL - 1) ? 1.f : 0.f;
+    else v = (r >= 1 && r <= ncov && c - G == r - 1) ? 1.f : 0.f;
     row[c] = v;
   }
 }
 
-// Hx[i] = [h[i, 0:HL] | 1 | X[i, G:G+ncov] | 0 ...] (width ldhx): the generator's last hidden activations of the step's z
-// batch, the constant of the output bias and the rows' covariate columns
+// blocks [0, B): Hx[i] = [1 | X[i, G:G+ncov] | 0 .. he | h[i, 0:HL] | 0 ...] (width ldhx) - the constant of the output
+// bias, the row's covariate columns, the generator's last hidden activations of the step's z batch: the column order is
+// the row order of ff_stage_kernel.  Blocks [B, B + he): the first he rows of the headroom's first-layer image P
+// [.., ldp], which need no product: row 0 = b_out . W_g = the ntile partial rows of wt_rows_kernel added up in order,
+// rows 1..ncov = the covariate rows of W_1 themselves, the rest 0.
 __global__ void __launch_bounds__(256) ff_hx_kernel(const float *__restrict__ hrows, int ldh, int HL, const float *__restrict__ X,
-                                                    int ldx, int G, int ncov, float *__restrict__ Hx, int ldhx, int B) {
+                                                    int ldx, int G, int ncov, int he, float *__restrict__ Hx, int ldhx, int B,
+                                                    const float *__restrict__ bpart, int ntile, const float *__restrict__ W1,
+                                                    int ldw, int H1, float *__restrict__ P, int ldp) {
   const int i = blockIdx.x;
+  if (i >= B + he) {
+    // row 0, 16 columns per block: 16 phases over the tiles (every load of a thread in flight together - one thread per
+    // column walked the 284 tiles of the GTEx shape in 20 us), the phases added in order
+    __shared__ float ph[16][16];
+    const int cl = threadIdx.x & 15, p16 = threadIdx.x >> 4, c = (i - B - he) * 16 + cl;
+    float q = 0.f;
+    if (c < H1)
+      for (int t = p16; t < ntile; t += 16) q += bpart[(size_t)t * H1 + c];
+    ph[p16][cl] = q;
+    __syncthreads();
+    if (p16 == 0 && c < H1) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += ph[k][cl];
+      P[c] = v;
+    }
+    return;
+  }
+  if (i >= B) {
+    const int r = i - B;
+    if (r == 0) return;   // (the blocks above)
+    for (int c = threadIdx.x; c < H1; c += 256)
+      P[(size_t)r * ldp + c] = r <= ncov ? W1[(size_t)(G + r - 1) * ldw + c] : 0.f;
+    return;
+  }
   for (int c = threadIdx.x; c < ldhx; c += 256) {
     float v = 0.f;
-    if (c < HL) v = hrows[(size_t)i * ldh + c];
-    else if (c == HL) v = 1.f;
-    else if (c < HL + 1 + ncov) v = X[(size_t)i * ldx + G + (c - HL - 1)];
+    if (c == 0) v = 1.f;
+    else if (c <= ncov) v = X[(size_t)i * ldx + G + (c - 1)];
+    else if (c >= he && c < he + HL) v = hrows[(size_t)i * ldh + (c - he)];
     Hx[(size_t)i * ldhx + c] = v;
   }
 }
@@ -1155,29 +1195,32 @@ extern "C" int agx_critic_head(void *stream, const float *A, int32_t lda, const 
   return AGX_OK;
 }
 
-int agx::wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov) {
-  AGX_CHECK_ARG(W && Xt && G > 0 && H > 0 && ldw >= H && ldx >= G + ncov && ncov >= 0, "wt_rows: bad argument");
+int agx::wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov, const float *bvec,
+                 float *bpart) {
+  AGX_CHECK_ARG(W && Xt && G > 0 && H > 0 && ldw >= H && ldx >= G + ncov && ncov >= 0 && (!bvec || bpart), "wt_rows: bad argument");
   agx::ProfScope prof(agx::as_stream(stream), AGX_K_DISC_DX, 0.0, 8.0 * G * (double)H);
   hipLaunchKernelGGL(wt_rows_kernel, dim3(agx::cdiv(G, 64), agx::cdiv(H, 64)), dim3(256), 0, agx::as_stream(stream), W, ldw, G, H,
-                     Xt, ldx, ncov);
+                     Xt, ldx, ncov, bvec, bpart);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
 
-int agx::ff_stage(void *stream, const float *Wout, int ldw, const float *bout, int HL, int G, int ncov, float *Xhd, int ldx,
-                  int rows) {
-  AGX_CHECK_ARG(Wout && bout && Xhd && HL > 0 && G > 0 && ncov >= 0 && ldw >= G && ldx >= G + ncov && rows >= HL + 1 + ncov,
-                "ff_stage: bad argument");
+int agx::ff_stage(void *stream, const float *Wout, int ldw, const float *bout, int HL, int G, int ncov, int he, float *Xhd,
+                  int ldx, int rows) {
+  AGX_CHECK_ARG(Wout && bout && Xhd && HL > 0 && G > 0 && ncov >= 0 && ldw >= G && ldx >= G + ncov && he >= 1 + ncov &&
+                    rows >= he + HL, "ff_stage: bad argument");
   hipLaunchKernelGGL(ff_stage_kernel, dim3(std::min(agx::cdiv(G + ncov, 256), 16), rows), dim3(256), 0, agx::as_stream(stream),
-                     Wout, ldw, bout, HL, G, ncov, Xhd, ldx);
+                     Wout, ldw, bout, HL, G, ncov, he, Xhd, ldx);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
 
-int agx::ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, float *Hx, int ldhx,
-               int B) {
-  AGX_CHECK_ARG(hrows && X && Hx && B > 0 && ldh >= HL && ldhx >= HL + 1 + ncov, "ff_hx: bad argument");
-  hipLaunchKernelGGL(ff_hx_kernel, dim3(B), dim3(256), 0, agx::as_stream(stream), hrows, ldh, HL, X, ldx, G, ncov, Hx, ldhx, B);
+int agx::ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, int he, float *Hx,
+               int ldhx, int B, const float *bpart, int ntile, const float *W1, int ldw, int H1, float *P, int ldp) {
+  AGX_CHECK_ARG(hrows && X && Hx && B > 0 && ldh >= HL && he >= 1 + ncov && ldhx >= he + HL && bpart && ntile > 0 && W1 && P &&
+                    ldw >= H1 && ldp >= H1, "ff_hx: bad argument");
+  hipLaunchKernelGGL(ff_hx_kernel, dim3(B + he + agx::cdiv(H1, 16)), dim3(256), 0, agx::as_stream(stream), hrows, ldh, HL, X, ldx, G, ncov, he, Hx,
+                     ldhx, B, bpart, ntile, W1, ldw, H1, P, ldp);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }

@@ -22,6 +22,9 @@ def shapes_for(name):
         return [('gram W^T W    TN', H, H, G, 1, 0), ('gram WT WT^T  NT', H, H, G, 0, 1), ('T = d1 M      NN', 512, H, H, 0, 0),
                 ('S = d1^T f d1 TN', H, H, 512, 1, 0), ('dw_in K=1280  TN', Dd, H, 1280, 1, 0), ('dw_in K=1536  TN', Dd, H, 1536, 1, 0),
                 ('disc_dx       NT', 512, G, H, 0, 1), ('gp2_in        NN', 512, H, G, 0, 0)]
+    if name == 'ff':     # factored fake rows: headroom + real rows through the critic's first layer
+        return [('hd+real 1032  NN', 1032, H, Dd, 0, 0), ('hd 520        NN', 520, H, Dd, 0, 0), ('real 512      NN', 512, H, Dd, 0, 0),
+                ('old fwd 1024  NN', 1024, H, Dd, 0, 0), ('dw_in K=1032  TN', Dd, H, 1032, 1, 0)]
     B = 512 if name == 'gtex512' else 32
     return [
         ('gen_fwd_out   NN', B, G, H, 0, 0),
