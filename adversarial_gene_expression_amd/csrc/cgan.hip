@@ -997,6 +997,7 @@ struct agx_iter_graph {
   agx::LrTable lrs;    // Adam: step sizes for the next replay (agx_cgan_iter_set_lr)
   agx::StageDraws sd = {};   // one-graph iterations: the draws ride the staging launch in front of the graph (sd.on)
   int split = 0, B_global = 0;
+  bool ff = false;     // recorded with factored fake rows (iter_ff): agx_cgan_dp_iteration's chunk launches follow
   // agx_cgan_dp_iteration: one event per row chunk of the large product + "exchange of the step done"
   hipEvent_t ev_chunk[AGX_MAX_DP_PIECES] = {};
   hipEvent_t ev_done = nullptr;
@@ -1021,6 +1022,16 @@ bool chain_input(const agx_cgan *h, const agx_iter_args_t *a) {
   for (int i = 0; i < dm.emb.n_cat; ++i)
     emb_end = std::max<int64_t>(emb_end, dm.emb.table_off[i] + (int64_t)dm.emb.vocab[i] * dm.emb.edim[i]);
   return emb_end <= 1024 && emb_end <= dm.w_off[0];
+}
+
+// Factored fake rows (critic_core / gen_core `ff`): iterations without augmentation at batches that take the Gram form
+// and the factored generator step.  The generator's output layer is linear, so neither the critic steps nor the generator
+// step need the generated rows themselves: the generator runs its hidden layers only, and [W_out; b_out] rides in front
+// of the stacked critic input (agx_cgan::HD).  One-GPU and data-parallel segments alike (the layer-1 weight-gradient
+// product is linear in each rank's own rows).  AGX_NO_FF (or AGX_NO_GRAM): off.
+bool iter_ff(const agx_cgan *h, const agx_iter_args_t *a) {
+  static const bool ff_off = getenv("AGX_NO_FF") != nullptr;
+  return !ff_off && a->nb_critic > 0 && gram_ok(h, a->B) && gen_fact_ok(h, a->B) && !a->aug_mask_disc && !a->aug_mask_gen;
 }
 
 // Records segment `seg` of the iteration (seg < 0: the whole iteration).  Segments end where a
@@ -1078,14 +1089,8 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   const bool rest = !getenv("AGX_NO_FUSED_REST");
   const int64_t dfull_hi = dm.w_off[0] + (int64_t)dm.dims[0] * dm.ldw[0];
   const bool rest_d = rest && dfull_hi % 4 == 0 && dfull_hi <= (dm.n_flat & ~(int64_t)3);
-  // Factored fake rows (critic_core / gen_core `ff`): the one-GPU RMSprop iteration without augmentation at batches that
-  // take the Gram form and the factored generator step.  The generator's output layer is linear, so neither the critic
-  // steps nor the generator step need the generated rows themselves: the generator runs its hidden layers only, and
-  // [W_out; b_out] rides in front of the stacked critic input (agx_cgan::HD).  AGX_NO_FF (or AGX_NO_GRAM): off.
-  static const bool ff_off = getenv("AGX_NO_FF") != nullptr;
-  const bool ff = !ff_off && seg < 0 && !a->split && nbc > 0 && !adam && gram_ok(h, B) && gen_fact_ok(h, B) && !a->aug_mask_disc &&
-                  !a->aug_mask_gen && rest && rest_d && fuse_g && can_fuse_d(h->HD + B);
-  if (ff) fuse_d = true;
+  const bool ff = iter_ff(h, a);
+  if (ff) fuse_d = can_fuse_d(h->HD + B);   // (the layer-1 weight-gradient product then runs over HD + B rows)
   if (rest_d) {
     dfo.rows = dm.dims[0];
     dfo.rest_w = h->dp; dfo.rest_g = h->dg; dfo.rest_s1 = a->disc_rms;
@@ -1284,6 +1289,7 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   g->snap = !a->split && !a->disc_losses && !a->gen_losses;
   g->adam = a->opt_kind == 1 && a->split < 2;   // split >= 2: the caller's optimizer launches take their step size from the host
   g->split = a->split;
+  g->ff = iter_ff(h, a);
   g->B_global = a->B_global > 0 ? a->B_global : a->B;
   g->chainx = chain_input(h, a);
   g->aug_mask = a->aug_mask_disc;
@@ -1423,16 +1429,18 @@ extern "C" int agx_cgan_iter_eager(agx_cgan_t *h, void *stream, const agx_iter_a
 namespace {
 // rows [r0, r1) of a step's largest weight-gradient product (critic: dW_1 = [a_0(real); a_0(fake); e_0]^T D_1 over the
 // 3B stacked rows; generator: dW_out = h_L^T dX over its B rows), same operands as critic_core / gen_core use
-int big_grad_chunk(agx_cgan *h, hipStream_t st, bool gen, int r0, int r1, int B, int gen_row0) {
+int big_grad_chunk(agx_cgan *h, hipStream_t st, bool gen, int r0, int r1, int B, int gen_row0, bool ff) {
   const agx_mlp_desc_t &m = gen ? h->cfg.gen : h->cfg.disc;
   const int l = gen ? m.n_layers - 1 : 0;
   const bool gfact = gen && gen_fact_ok(h, B);   // (gen_core: dW_out = Q-as-TN . W_g^T, W_g^T in the rows the input gradient would take)
-  const float *in = gen ? (gfact ? h->genQ : h->gh[l] + (size_t)gen_row0 * h->ldgh[l]) : h->Xbuf[0];
+  // (ff, critic_core / gen_core: the critic's product starts HD rows in front of X and D_1; W_g^T sits right in front of X)
+  const float *in = gen ? (gfact ? h->genQ : h->gh[l] + (size_t)gen_row0 * h->ldgh[l]) : h->Xbuf[0] - (ff ? (size_t)h->HD * h->ldx : 0);
   const int ldin = gen ? (gfact ? h->ldpt : h->ldgh[l]) : h->ldx;
-  const float *dl = gen ? h->Xbuf[0] + (size_t)B * h->ldx : h->D[1];
+  const float *dl = gen ? (ff ? h->Xbuf[0] - (size_t)h->cfg.disc.dims[1] * h->ldx : h->Xbuf[0] + (size_t)B * h->ldx)
+                        : h->D[1] - (ff ? (size_t)h->HD * h->ldh[1] : 0);
   const int ldd = gen ? h->ldx : h->ldh[1];
   float *out = (gen ? h->gg : h->dg) + m.w_off[l];
-  Gemm g(h, in + r0, ldin, 1, dl, ldd, 0, out + (size_t)r0 * m.ldw[l], m.ldw[l], r1 - r0, m.dims[l + 1], gen ? gen_dw_rows(h, B) : dw1_rows(h, B));
+  Gemm g(h, in + r0, ldin, 1, dl, ldd, 0, out + (size_t)r0 * m.ldw[l], m.ldw[l], r1 - r0, m.dims[l + 1], gen ? gen_dw_rows(h, B) : (ff ? h->HD + B : dw1_rows(h, B)));
   return g.id(gen ? AGX_K_GEN_DW_OUT : AGX_K_DISC_DW_IN).sk(true).run(st);
 }
 
@@ -1484,7 +1492,7 @@ extern "C" int agx_cgan_dp_iteration(agx_iter_graph_t *g, void *stream, void *co
     if (s > 0) AGX_HIP(hipStreamWaitEvent(cs, g->ev_done, 0));   // the parameters of step s - 1 are in place
     AGX_HIP(hipGraphLaunch(g->exec[s], cs));
     for (int c = 0; c < n.n_pieces; ++c) {
-      AGX_TRY(big_grad_chunk(h, cs, gen, n.rows[c], n.rows[c + 1], B, nbc * B));
+      AGX_TRY(big_grad_chunk(h, cs, gen, n.rows[c], n.rows[c + 1], B, nbc * B, g->ff));
       AGX_HIP(hipEventRecord(g->ev_chunk[c], cs));
     }
     for (int c = 0; c < n.n_pieces; ++c) {
