@@ -27,6 +27,10 @@
 // * Inside a captured iteration the generator weights are constant over the nb_critic critic
 //   steps and the generator step (they change only at the iteration's end), so the generator
 //   runs ONCE on the nb_critic+1 stacked z batches; each step picks up its block of fake rows.
+// * Batches of at least 1.5 x the hidden widths never form a B x G matrix other than the real rows (gram_ok,
+//   gen_fact_ok, iter_ff below): the penalty's input-gradient terms go through the Gram matrix of W_1's gene rows, the
+//   generator's linear output layer (tf_utils.py:88) lets W_out W_g stand in for the generated rows.  Same algebra,
+//   other rounding order; DESIGN.md section 3 "Large batches".
 #include "agx_common.h"
 
 #include <algorithm>
