@@ -1116,7 +1116,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
                      agx::gemm_can_dual(S * B, gm0.dims[Lg0 + 1], gm0.dims[Lg0], h->skws_floats, 0);
   auto stage_now = [&](const agx::StageDraws *sd) -> int {
     const int ncat = gm0.emb.n_cat, nnum = gm0.n_num;
-    return agx::iter_stage(st, hook->x, hook->ldx, h->Xbuf[0], chain_input(h, a) ? h->Xbuf[1] : nullptr, h->ldx, h->G, B,
+    return agx::iter_stage(st, hook->x, hook->ldx, h->Xbuf[0], (chain_input(h, a) && !ff) ? h->Xbuf[1] : nullptr, h->ldx, h->G, B,
                            hook->cat, h->scat, B * ncat, hook->num, h->snum, B * nnum, h->rngpos, hook->rng_offset,
                            h->loss_slot, hook->losses_out, hook->lrs, h->lrdev, a->aug_mask_disc, a->aug_noise_real, h->G, sd);
   };
@@ -1295,7 +1295,7 @@ extern "C" int agx_cgan_iter_capture(agx_cgan_t *h, void *stream, const agx_iter
   g->split = a->split;
   g->ff = iter_ff(h, a);
   g->B_global = a->B_global > 0 ? a->B_global : a->B;
-  g->chainx = chain_input(h, a);
+  g->chainx = chain_input(h, a) && !iter_ff(h, a);   // (factored fake rows: one stacked-input buffer)
   g->aug_mask = a->aug_mask_disc;
   g->aug_noise_real = a->aug_noise_real;
   g->lrs.n = 0;
