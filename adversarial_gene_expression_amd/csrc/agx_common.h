@@ -100,8 +100,9 @@ int wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int 
 // and the per-step [h | 1 | covariates] rows (elementwise.hip)
 int ff_stage(void *stream, const float *Wout, int ldw, const float *bout, int HL, int G, int ncov, int he, float *Xhd, int ldx,
              int rows);
-int ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, int he, float *Hx, int ldhx,
-          int B, const float *bpart, int ntile, const float *W1, int ldw, int H1, float *P, int ldp);
+int ff_hx(void *stream, const float *hrows, int ldh, int HL, float *X, int ldx, int G, int ncov, int he, float *Hx, int ldhx,
+          int B, const float *bpart, int ntile, const float *W1, int ldw, int H1, float *P, int ldp, const agx_embed_t *e,
+          const float *tables, const float *num, int n_num, const int32_t *cat);
 // true if the heuristic launches the TN product dW[M,N] (K rows) on a kernel that has the fused
 // epilogue, without split-K (then fused and unfused runs sum in the same order: bit-identical)
 bool gemm_can_fuse_opt(int M, int N, int K, int64_t ws_floats);

@@ -548,10 +548,11 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     // W_g^T behind the W_out rows (and the tiles' shares of b_out . W_g); then ONE product: rows he.. of the headroom
     // and the real rows through the first layer (GTEx at 512 rows: 1024 rows, the shape of the old [real; fake] forward)
     AGX_TRY(agx::wt_rows(st, W1, m.ldw[0], G, H1, Xhd + (size_t)hxp * ldx, ldx, h->ncov, h->gp + gm.b_off[Lg], h->ffBp));
+    // (also the step's refresh of the real rows' covariate columns from the just-updated tables: before the product)
+    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)h->ff_row0 * h->ldgh[Lg], h->ldgh[Lg], gm.dims[Lg], h->X, ldx, G, h->ncov, he,
+                       h->ffHx, h->ldhx, B, h->ffBp, h->ntile, W1, m.ldw[0], H1, h->ffP, ldp, &m.emb, h->dp, h->snum, m.n_num, cat));
     AGX_TRY(Gemm(h, Xhd + (size_t)he * ldx, ldx, 0, W1, m.ldw[0], 0, h->ffP + (size_t)he * ldp, ldp, HD - he + B, H1, m.dims[0])
                 .id(AGX_K_DISC_FWD_IN).run(st));
-    AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)h->ff_row0 * h->ldgh[Lg], h->ldgh[Lg], gm.dims[Lg], h->X, ldx, G, h->ncov, he,
-                       h->ffHx, h->ldhx, B, h->ffBp, h->ntile, W1, m.ldw[0], H1, h->ffP, ldp));
     AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, ldp, 0, h->ffAf, H1, B, H1, hx).id(AGX_K_DISC_FWD_HID).run(st));
     // the tail takes the real rows' finished values as ONE slab (ffP is compact: ldp = H1) and the fake rows' from ffAf
     AGX_TRY(tail_forward(h, st, 1, B, B, alpha, B, B, -invb, invb, 1.f, &out_parts, h->ffP + (size_t)HD * ldp, h->ffAf));
@@ -726,7 +727,7 @@ int gen_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_globa
     AGX_TRY(Gemm(h, Xhd + (size_t)h->he * ldx, ldx, 0, W1, m.ldw[0], 0, h->ffP + (size_t)h->he * h->ldp, h->ldp, HLg, H1c,
                  m.dims[0]).id(AGX_K_DISC_FWD_IN).run(st));
     AGX_TRY(agx::ff_hx(st, h->gh[Lg] + (size_t)gen_row0 * h->ldgh[Lg], h->ldgh[Lg], HLg, h->X, ldx, G, h->ncov, h->he, h->ffHx,
-                       h->ldhx, B, h->ffBp, h->ntile, W1, m.ldw[0], H1c, h->ffP, h->ldp));
+                       h->ldhx, B, h->ffBp, h->ntile, W1, m.ldw[0], H1c, h->ffP, h->ldp, &m.emb, h->dp, h->snum, m.n_num, cat));
     AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 0, h->ffP, h->ldp, 0, h->ffAf, H1c, B, H1c, h->hx).id(AGX_K_DISC_FWD_HID).run(st));
     AGX_TRY(tail_forward(h, st, 1, B, 0, nullptr, B, 0, -invb, 0.f, 0.f, &out_parts, h->ffAf));
   } else {
@@ -1218,7 +1219,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
     if (in_seg(k)) {
       // covariate columns of [real; fake] from the CURRENT (just updated) embedding tables
       h->ff_row0 = k * B;
-      if (ff) AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));   // covariate columns of the real rows, current tables
+      if (ff) {}   // (critic_core refreshes the real rows' covariate columns itself: ff_hx)
       else
       if (!chainx || (k == 0 && !fold0)) AGX_TRY(place_fake(k, st, true));
       agx::FusedOpt dk = dfo;
@@ -1248,7 +1249,7 @@ int record_iteration(agx_cgan *h, hipStream_t st, const agx_iter_args_t *a, int 
   }
   h->X = Xb[nbc & 1];
   if (in_seg(nbc)) {
-    if (ff) AGX_TRY(disc_cov_columns(h, st, h->scat, h->snum, B, B));
+    if (ff) {}   // (gen_core: ff_hx)
     else
     if (!chainx) AGX_TRY(place_fake(nbc, st, true));   // else: assembled by the last critic step's layer-1 product
     AGX_TRY(gen_core(h, st, h->scat, B, Bg, nbc * B, a->gen_losses ? a->gen_losses : h->losslog + 4 * nbc,

@@ -226,6 +226,21 @@ __global__ void __launch_bounds__(256) wt_rows_kernel(const float *__restrict__ 
     }
 }
 
+// covariate column c of source row b: [num | emb_0 | emb_1 ...] (tf_utils.py:120-131); an index outside its table gives 0
+__device__ __forceinline__ float cov_value(const agx_embed_t &e, const float *__restrict__ tables, const float *__restrict__ num,
+                                           int n_num, int ld_num, const int *__restrict__ cat, int ld_cat, int b, int c) {
+  if (c < n_num) return num[(size_t)b * ld_num + c];
+  c -= n_num;
+  for (int i = 0; i < e.n_cat; ++i) {
+    if (c < e.edim[i]) {
+      const int row = cat[(size_t)b * ld_cat + i];
+      return (row >= 0 && row < e.vocab[i]) ? tables[e.table_off[i] + (size_t)row * e.edim[i] + c] : 0.f;
+    }
+    c -= e.edim[i];
+  }
+  return 0.f;
+}
+
 // Factored fake rows (cgan.hip record_iteration `ff`): the rows in front of the stacked critic input, one block per row.
 //   r == 0: [b_out | 0]   1 <= r <= ncov: [0 | unit vector r - 1]   ncov < r < he: 0   he <= r < he + HL: [W_out[r - he] | 0]
 //   above: 0   (he = 1 + ncov rounded up to a multiple of 4: the W_out rows start a 16-byte-aligned block of rows)
@@ -242,15 +257,18 @@ __global__ void __launch_bounds__(256) ff_stage_kernel(const float *__restrict__
   }
 }
 
-// blocks [0, B): Hx[i] = [1 | X[i, G:G+ncov] | 0 .. he | h[i, 0:HL] | 0 ...] (width ldhx) - the constant of the output
-// bias, the row's covariate columns, the generator's last hidden activations of the step's z batch: the column order is
-// the row order of ff_stage_kernel.  Blocks [B, B + he): the first he rows of the headroom's first-layer image P
+// blocks [0, B): Hx[i] = [1 | covariates of row i | 0 .. he | h[i, 0:HL] | 0 ...] (width ldhx) - the constant of the
+// output bias, the row's covariate columns FROM THE CURRENT TABLES (also written into the real row's covariate columns of
+// X: the step's refresh, tf_utils.py:213-214 with the just-updated embeddings), the generator's last hidden activations of
+// the step's z batch: the column order is the row order of ff_stage_kernel.  Blocks [B, B + he): the first he rows of the headroom's first-layer image P
 // [.., ldp], which need no product: row 0 = b_out . W_g = the ntile partial rows of wt_rows_kernel added up in order,
 // rows 1..ncov = the covariate rows of W_1 themselves, the rest 0.
-__global__ void __launch_bounds__(256) ff_hx_kernel(const float *__restrict__ hrows, int ldh, int HL, const float *__restrict__ X,
+__global__ void __launch_bounds__(256) ff_hx_kernel(const float *__restrict__ hrows, int ldh, int HL, float *__restrict__ X,
                                                     int ldx, int G, int ncov, int he, float *__restrict__ Hx, int ldhx, int B,
                                                     const float *__restrict__ bpart, int ntile, const float *__restrict__ W1,
-                                                    int ldw, int H1, float *__restrict__ P, int ldp) {
+                                                    int ldw, int H1, float *__restrict__ P, int ldp, const agx_embed_t e,
+                                                    const float *__restrict__ tables, const float *__restrict__ num, int n_num,
+                                                    const int *__restrict__ cat) {
   const int i = blockIdx.x;
   if (i >= B + he) {
     // row 0, 16 columns per block: 16 phases over the tiles (every load of a thread in flight together - one thread per
@@ -280,7 +298,10 @@ __global__ void __launch_bounds__(256) ff_hx_kernel(const float *__restrict__ hr
   for (int c = threadIdx.x; c < ldhx; c += 256) {
     float v = 0.f;
     if (c == 0) v = 1.f;
-    else if (c <= ncov) v = X[(size_t)i * ldx + G + (c - 1)];
+    else if (c <= ncov) {
+      v = cov_value(e, tables, num, n_num, n_num, cat, e.n_cat, i, c - 1);
+      X[(size_t)i * ldx + G + (c - 1)] = v;
+    }
     else if (c >= he && c < he + HL) v = hrows[(size_t)i * ldh + (c - he)];
     Hx[(size_t)i * ldhx + c] = v;
   }
@@ -625,23 +646,8 @@ __global__ void __launch_bounds__(256) stack_rows_kernel(
   for (long long idx = ((long long)(blockIdx.y * nb + (blockIdx.x - gene_blocks))) * blockDim.x + threadIdx.x;
        idx < total; idx += (long long)nb * gridDim.y * blockDim.x) {
     const int r = (int)(idx / ncov);
-    const int b = r % B;
-    int c = (int)(idx % ncov);
-    float v = 0.f;
-    if (c < n_num) {
-      v = num[(size_t)b * ld_num + c];
-    } else {
-      c -= n_num;
-      for (int i = 0; i < e.n_cat; ++i) {
-        if (c < e.edim[i]) {
-          const int row = cat[(size_t)b * ld_cat + i];
-          if (row >= 0 && row < e.vocab[i]) v = tables[e.table_off[i] + (size_t)row * e.edim[i] + c];
-          break;
-        }
-        c -= e.edim[i];
-      }
-    }
-    X[(size_t)r * ldx + G + (int)(idx % ncov)] = v;
+    const int c = (int)(idx % ncov);
+    X[(size_t)r * ldx + G + c] = cov_value(e, tables, num, n_num, ld_num, cat, ld_cat, r % B, c);
   }
 }
 
@@ -1215,12 +1221,16 @@ int agx::ff_stage(void *stream, const float *Wout, int ldw, const float *bout, i
   return AGX_OK;
 }
 
-int agx::ff_hx(void *stream, const float *hrows, int ldh, int HL, const float *X, int ldx, int G, int ncov, int he, float *Hx,
-               int ldhx, int B, const float *bpart, int ntile, const float *W1, int ldw, int H1, float *P, int ldp) {
+int agx::ff_hx(void *stream, const float *hrows, int ldh, int HL, float *X, int ldx, int G, int ncov, int he, float *Hx,
+               int ldhx, int B, const float *bpart, int ntile, const float *W1, int ldw, int H1, float *P, int ldp,
+               const agx_embed_t *e, const float *tables, const float *num, int n_num, const int32_t *cat) {
   AGX_CHECK_ARG(hrows && X && Hx && B > 0 && ldh >= HL && he >= 1 + ncov && ldhx >= he + HL && bpart && ntile > 0 && W1 && P &&
-                    ldw >= H1 && ldp >= H1, "ff_hx: bad argument");
+                    ldw >= H1 && ldp >= H1 && e && tables && (n_num == 0 || num) && (e->n_cat == 0 || cat), "ff_hx: bad argument");
+  int ec = n_num;
+  for (int i = 0; i < e->n_cat; ++i) ec += e->edim[i];
+  AGX_CHECK_ARG(ec == ncov, "ff_hx: %d covariate columns, the tables make %d", ncov, ec);
   hipLaunchKernelGGL(ff_hx_kernel, dim3(B + he + agx::cdiv(H1, 16)), dim3(256), 0, agx::as_stream(stream), hrows, ldh, HL, X, ldx, G, ncov, he, Hx,
-                     ldhx, B, bpart, ntile, W1, ldw, H1, P, ldp);
+                     ldhx, B, bpart, ntile, W1, ldw, H1, P, ldp, *e, tables, num, n_num, cat);
   AGX_LAUNCH_CHECK();
   return AGX_OK;
 }
