@@ -51,6 +51,10 @@ CONFIGS = {
     'ecoli_1076': dict(G=1076, V=EC_V, H=(128, 128), Z=10, B=32, p_aug=0.25),
     'ecoli_4297': dict(G=4297, V=EC_V, H=(128, 128), Z=10, B=32, p_aug=0.25),
     'wide_b32': dict(G=20000, V=(15, 3), H=(1024, 1024), Z=64, B=32, p_aug=0),
+    # factored fake rows (cgan.hip iter_ff) at widths that leave padding rows in the headroom (he + HL = 8 + 18 = 26 -> 28)
+    # and at the E. coli gene count with 22 covariate columns and hidden widths that are no multiple of 64
+    'ff_odd_widths': dict(G=130, V=(15, 3), H=(22, 18), Z=6, B=40, p_aug=0, nbc=3),
+    'ff_ecoli_b256': dict(G=4297, V=EC_V, H=(160, 144), Z=10, B=256, p_aug=0, nbc=2),
 }
 
 
