@@ -572,6 +572,11 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   }
   AGX_TRY(disc_backward_chain(h, st, R));
   float *D1i = h->D[1] + (size_t)2 * B * h->ldh[1];
+  // (the layer-1 weight-gradient product comes LAST when it carries the flat update, see below)
+  const bool dw1_last = fo && fo->rest_n > 0;
+  // hidden-layer products of a few 32x32 tiles over K = 3B rows ride the small-gradient launch
+  agx::TnJobs tn;
+  tn.n = 0;
   const bool gram = tail && gram_ok(h, B);
   h->dw1_rows = ff ? HD + B : dw1_rows(h, B);
   AGX_CHECK_ARG(!ff || gram, "critic_core: factored fake rows without the Gram form");
@@ -601,11 +606,18 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     t.nsplit = tail_nsplit((B + 3) / 4);
     t.gram = 1; t.gU = h->gramU; t.gF = h->gramF; t.ldg = ldh1;
     AGX_TRY(agx::critic_tail(st, 1, t));
-    // S in front of the real rows' deltas (ff) / over the first H1 inter rows
-    AGX_TRY(Gemm(h, h->gramU, ldh1, 1, h->gramF, ldh1, 0, ff ? Dhd + (size_t)hxp * ldh1 : D1i, ldh1, H1, H1, B)
-                .id(AGX_K_GP2_IN).run(st));
-    if (ff)   // the fake rows' term of dW_1: [W_out; b_out; unit rows]^T . (Hx^T d_1(fake))
+    // S in front of the real rows' deltas (ff) / over the first H1 inter rows; ff: the fake rows' term of dW_1,
+    // [W_out; b_out; unit rows]^T . (Hx^T d_1(fake)).  Where the layer-1 product is the step's last launch both ride the
+    // small-gradient launch in front of it (one wave per 32x32 tile over the B rows: two launches of ~7 us less)
+    float *Sout = ff ? Dhd + (size_t)hxp * ldh1 : D1i;
+    if (ff && dw1_last && tn_fuse() && B <= 512 && tn.n + 2 <= AGX_MAX_LAYERS) {
+      tn.job[tn.n++] = agx::TnJobs::Job{h->gramU, h->gramF, Sout, ldh1, ldh1, ldh1, H1, H1, B};
+      tn.job[tn.n++] = agx::TnJobs::Job{h->ffHx, h->D[1] + (size_t)B * ldh1, Dhd, h->ldhx, ldh1, ldh1, hx, H1, B};
+    } else {
+    AGX_TRY(Gemm(h, h->gramU, ldh1, 1, h->gramF, ldh1, 0, Sout, ldh1, H1, H1, B).id(AGX_K_GP2_IN).run(st));
+    if (ff)
       AGX_TRY(Gemm(h, h->ffHx, h->ldhx, 1, h->D[1] + (size_t)B * ldh1, ldh1, 0, Dhd, ldh1, hx, H1, B).id(AGX_K_GP2_IN).run(st));
+    }
   } else {
   // g = d_1 . W_1[:G]^T -> inter rows of X, with the per-slab row sums of squares as a side
   // output of the epilogue                                                      :168-169
@@ -656,10 +668,6 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
   // With the flat update appended to the layer-1 product (fo->rest_n), that launch must come LAST:
   // it overwrites the covariate rows of W_1 the embedding gradient reads and needs every other
   // gradient of the step complete.
-  const bool dw1_last = fo && fo->rest_n > 0;
-  // hidden-layer products of a few 32x32 tiles over K = 3B rows ride the small-gradient launch
-  agx::TnJobs tn;
-  tn.n = 0;
   auto weight_grad = [&](int l) -> int {
     if (l == 0 && h->skip_big) return AGX_OK;   // launched in row chunks by agx_cgan_dp_iteration (big_grad_chunk)
     const float *in = l == 0 ? (ff ? Xhd : h->X) : h->A[l];
