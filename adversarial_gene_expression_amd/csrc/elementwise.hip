@@ -743,7 +743,10 @@ __device__ __forceinline__ void colsum_block(const float *__restrict__ A, int ld
 // four accumulators that are added at the end: a fixed summation order).  Lane (i = lane & 31, h = lane >> 5) feeds k = 8g + 4h + e of
 // row / column i, the same k for both operands; loads are clamped into the operands and masked after.
 typedef float tn_f32x16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile) {
+// (kb, ke: the k range of this wave - the whole K, or a quarter of it where a block's four waves share one tile of a
+//  long-K job, tn_split_k; store: write C, else leave the sums in acc)
+__device__ __forceinline__ bool tn_split_k(int K) { return K > 256; }
+__device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile, int kb, int ke, bool store, float *acc_out) {
   const int tiles_n = (t.N + 31) / 32;
   if (tile >= ((t.M + 31) / 32) * tiles_n) return;
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
@@ -759,14 +762,14 @@ __device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
   constexpr int U = 6;
-  const int ngroups = (t.K + 7) / 8, kl = t.K - 1;
+  const int ngroups = (max(ke - kb, 0) + 7) / 8, kl = ke - 1;
   for (int g0 = 0; g0 < ngroups; g0 += U) {
     float av[U][4], bv[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int kc = min(8 * (g0 + u) + 4 * h + e, kl);
+        const int kc = max(min(kb + 8 * (g0 + u) + 4 * h + e, kl), 0);
         av[u][e] = a[(size_t)kc * t.lda];
         bv[u][e] = b[(size_t)kc * t.ldb];
       }
@@ -774,13 +777,24 @@ __device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool kv = 8 * (g0 + u) + 4 * h + e <= kl;
+        const bool kv = kb + 8 * (g0 + u) + 4 * h + e <= kl;
         acc4[e] = __builtin_amdgcn_mfma_f32_32x32x2f32((kv && mv) ? av[u][e] : 0.f, (kv && nv) ? bv[u][e] : 0.f, acc4[e], 0, 0, 0);
       }
   }
   tn_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+  if (!store) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_out[r] = acc[r];
+    return;
+  }
+  if (acc_out) {   // the other waves' quarters, in wave order
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += acc_out[(w * 16 + r) * 64 + lane];
+  }
   if (nv) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -831,7 +845,23 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const SmallPlan plan,
   if (kind == 0) {
     // the tiny weight-gradient products, 4 tiles per block - one wave per SIMD (16 tiles
     // on one CU queue 4 waves' MFMAs per SIMD: the launch grew from 8.5 to 13 us); waves 4..15 leave
-    if (threadIdx.x < 256) tn_wave_tile(tn.job[jidx], blk * 4 + (int)(threadIdx.x >> 6));
+    const agx::TnJobs::Job &t = tn.job[jidx];
+    if (tn_split_k(t.K)) {
+      // long K (S and Hx^T d_1 at 512 rows: 22 us as one wave per tile): the block's four waves take a quarter of K each,
+      // waves 1..3 leave their sums in LDS, wave 0 adds them in wave order and stores
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const int kq = (((t.K + 3) / 4) + 7) & ~7;
+      if (w >= 1 && w < 4) {
+        float part[16];
+        tn_wave_tile(t, blk, w * kq, min(t.K, (w + 1) * kq), false, part);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) svec[((w - 1) * 16 + r) * 64 + lane] = part[r];
+      }
+      __syncthreads();
+      if (w == 0) tn_wave_tile(t, blk, 0, min(t.K, kq), true, svec);
+      return;
+    }
+    if (threadIdx.x < 256) tn_wave_tile(t, blk * 4 + (int)(threadIdx.x >> 6), 0, t.K, true, nullptr);
     return;
   }
   if (kind == 1) {
@@ -1522,6 +1552,12 @@ extern "C" int agx_small_grads(void *stream, const agx_small_grads_t *j) {
   return agx::small_grads_run(stream, j, agx::LossCopy{nullptr, nullptr, 0});
 }
 
+// blocks of a product job: four tiles per block, or one where the block's four waves split a long K (tn_split_k)
+static int tn_blocks(const agx::TnJobs::Job &t) {
+  const int tiles = agx::cdiv(t.M, 32) * agx::cdiv(t.N, 32);
+  return t.K > 256 ? tiles : agx::cdiv(tiles, 4);
+}
+
 int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::LossCopy &lc, const agx::TnJobs *tn) {
   AGX_CHECK_ARG(j && j->n_colsum >= 0 && j->n_colsum <= AGX_MAX_LAYERS, "agx_small_grads: bad job list");
   int blocks = 0;
@@ -1534,7 +1570,7 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
       const agx::TnJobs::Job &t = tj.job[q];
       AGX_CHECK_ARG(t.A && t.B && t.C && t.M > 0 && t.N > 0 && t.K > 0 && t.lda >= t.M && t.ldb >= t.N && t.ldc >= t.N &&
                         t.K <= 512 && (int64_t)agx::cdiv(t.M, 32) * agx::cdiv(t.N, 32) <= 256, "agx_small_grads: product job %d", q);
-      blocks += agx::cdiv(agx::cdiv(t.M, 32) * agx::cdiv(t.N, 32), 4);
+      blocks += tn_blocks(t);
     }
   }
   for (int c = 0; c < j->n_colsum; ++c) {
@@ -1581,7 +1617,7 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
       coff += j->emb.edim[i];
     }
   }
-  for (int q = 0; q < tj.n; ++q) seg(0, q, 0, agx::cdiv(agx::cdiv(tj.job[q].M, 32) * agx::cdiv(tj.job[q].N, 32), 4));
+  for (int q = 0; q < tj.n; ++q) seg(0, q, 0, tn_blocks(tj.job[q]));
   if (j->l_losses) seg(4, 0, 0, 1);
   if (j->w_A) seg(2, 0, 0, agx::cdiv(j->w_H, 64));
   for (int c = 0; c < j->n_colsum; ++c) seg(1, c, 0, agx::cdiv(j->cs_H[c], 64));
