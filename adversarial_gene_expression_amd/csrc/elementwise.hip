@@ -1238,10 +1238,66 @@ extern "C" int agx_critic_head(void *stream, const float *A, int32_t lda, const 
   return AGX_OK;
 }
 
+// the same with 16-byte accesses on both sides (4 loads + 4 stores per thread instead of 16 + 16): needs ldw, ldx
+// multiples of 4, 16-byte-aligned bases and ldx >= G rounded up to 4 (a tile's last float4 may reach up to 3 columns past
+// G: zeros, into covariate / padding columns that hold zeros anyway)
+__global__ void __launch_bounds__(256) wt_rows4_kernel(const float *__restrict__ W, int ldw, int G, int H,
+                                                       float *__restrict__ Xt, int ldx, int ncov,
+                                                       const float *__restrict__ bvec, float *__restrict__ bpart) {
+  __shared__ float t[64][65];
+  __shared__ float bp[16][64];
+  const int c4 = threadIdx.x & 15, rq = threadIdx.x >> 4;
+  const int g0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rq + 16 * q, g = g0 + r, hh = h0 + 4 * c4;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < G && hh < H) w = *reinterpret_cast<const float4 *>(W + (size_t)g * ldw + hh);   // (columns H.. of the last float4: padding of W, masked)
+    if (hh + 1 >= H) w.y = 0.f;
+    if (hh + 2 >= H) w.z = 0.f;
+    if (hh + 3 >= H) w.w = 0.f;
+    t[r][4 * c4] = w.x; t[r][4 * c4 + 1] = w.y; t[r][4 * c4 + 2] = w.z; t[r][4 * c4 + 3] = w.w;
+    if (bvec) {
+      const float b = g < G ? bvec[g] : 0.f;
+      bs[0] += b * w.x; bs[1] += b * w.y; bs[2] += b * w.z; bs[3] += b * w.w;
+    }
+  }
+  if (bvec) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bp[rq][4 * c4 + e] = bs[e];
+  }
+  __syncthreads();
+  if (bvec && threadIdx.x < 64 && h0 + (int)threadIdx.x < H) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += bp[k][threadIdx.x];
+    bpart[(size_t)blockIdx.x * H + h0 + threadIdx.x] = v;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rq + 16 * q, hh = h0 + r, g = g0 + 4 * c4;
+    if (hh < H && g < G)
+      *reinterpret_cast<float4 *>(Xt + (size_t)hh * ldx + g) = make_float4(t[4 * c4][r], t[4 * c4 + 1][r], t[4 * c4 + 2][r], t[4 * c4 + 3][r]);
+  }
+  if (blockIdx.x == 0)
+    for (int q = threadIdx.x; q < 64 * ncov; q += 256) {
+      const int hh = h0 + q / ncov;
+      if (hh < H) Xt[(size_t)hh * ldx + G + q % ncov] = 0.f;
+    }
+}
+
 int agx::wt_rows(void *stream, const float *W, int ldw, int G, int H, float *Xt, int ldx, int ncov, const float *bvec,
                  float *bpart) {
   AGX_CHECK_ARG(W && Xt && G > 0 && H > 0 && ldw >= H && ldx >= G + ncov && ncov >= 0 && (!bvec || bpart), "wt_rows: bad argument");
   agx::ProfScope prof(agx::as_stream(stream), AGX_K_DISC_DX, 0.0, 8.0 * G * (double)H);
+  // (the last float4 of a row may reach 3 columns past G: they must be columns this call zeroes anyway, or padding)
+  const bool v4 = ldw % 4 == 0 && ldx % 4 == 0 && agx::aligned16(W) && agx::aligned16(Xt) && ldx >= ((G + 3) & ~3) &&
+                  (ncov == 0 ? false : ((G + 3) & ~3) - G <= ncov);
+  if (v4)
+    hipLaunchKernelGGL(wt_rows4_kernel, dim3(agx::cdiv(G, 64), agx::cdiv(H, 64)), dim3(256), 0, agx::as_stream(stream), W, ldw, G, H,
+                       Xt, ldx, ncov, bvec, bpart);
+  else
   hipLaunchKernelGGL(wt_rows_kernel, dim3(agx::cdiv(G, 64), agx::cdiv(H, 64)), dim3(256), 0, agx::as_stream(stream), W, ldw, G, H,
                      Xt, ldx, ncov, bvec, bpart);
   AGX_LAUNCH_CHECK();
