@@ -672,7 +672,11 @@ int critic_core(agx_cgan *h, hipStream_t st, const int32_t *cat, int B, int B_gl
     if (l == 0 && h->skip_big) return AGX_OK;   // launched in row chunks by agx_cgan_dp_iteration (big_grad_chunk)
     const float *in = l == 0 ? (ff ? Xhd : h->X) : h->A[l];
     const int ldin = l == 0 ? ldx : h->ldh[l];
-    if (l > 0 && tn_fuse() && agx::tn_job_ok(m.dims[l], m.dims[l + 1], R)) {
+    // (where the layer-1 product is the step's last launch, also over up to 2048 rows: the launch splits a long K over
+    //  a block's waves, 6 us of product + 5 us of slab reduce less per step at 512 rows)
+    if (l > 0 && tn_fuse() && tn.n < AGX_MAX_LAYERS &&
+        (agx::tn_job_ok(m.dims[l], m.dims[l + 1], R) ||
+         (dw1_last && R <= 2048 && agx::cdiv(m.dims[l], 32) * agx::cdiv(m.dims[l + 1], 32) <= 256))) {
       tn.job[tn.n++] = agx::TnJobs::Job{in, h->D[l + 1], h->dg + m.w_off[l], ldin, h->ldh[l + 1], m.ldw[l],
                                         m.dims[l], m.dims[l + 1], R};
       return AGX_OK;

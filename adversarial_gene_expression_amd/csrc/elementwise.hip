@@ -789,9 +789,9 @@ __device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile
     for (int r = 0; r < 16; ++r) acc_out[r] = acc[r];
     return;
   }
-  if (acc_out) {   // the other waves' quarters, in wave order
-#pragma unroll
-    for (int w = 0; w < 3; ++w)
+  if (acc_out) {   // the other waves' shares, in wave order
+    const int nother = t.K > 1024 ? 7 : 3;
+    for (int w = 0; w < nother; ++w)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += acc_out[(w * 16 + r) * 64 + lane];
   }
@@ -850,8 +850,9 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const SmallPlan plan,
       // long K (S and Hx^T d_1 at 512 rows: 22 us as one wave per tile): the block's four waves take a quarter of K each,
       // waves 1..3 leave their sums in LDS, wave 0 adds them in wave order and stores
       const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      const int kq = (((t.K + 3) / 4) + 7) & ~7;
-      if (w >= 1 && w < 4) {
+      const int nw = t.K > 1024 ? 8 : 4;   // (eight shares from 1024 rows on: the hidden-layer gradient over 3B = 1536 rows)
+      const int kq = (((t.K + nw - 1) / nw) + 7) & ~7;
+      if (w >= 1 && w < nw) {
         float part[16];
         tn_wave_tile(t, blk, w * kq, min(t.K, (w + 1) * kq), false, part);
 #pragma unroll
@@ -1625,7 +1626,7 @@ int agx::small_grads_run(void *stream, const agx_small_grads_t *j, const agx::Lo
     for (int q = 0; q < tj.n; ++q) {
       const agx::TnJobs::Job &t = tj.job[q];
       AGX_CHECK_ARG(t.A && t.B && t.C && t.M > 0 && t.N > 0 && t.K > 0 && t.lda >= t.M && t.ldb >= t.N && t.ldc >= t.N &&
-                        t.K <= 512 && (int64_t)agx::cdiv(t.M, 32) * agx::cdiv(t.N, 32) <= 256, "agx_small_grads: product job %d", q);
+                        t.K <= 2048 && (int64_t)agx::cdiv(t.M, 32) * agx::cdiv(t.N, 32) <= 256, "agx_small_grads: product job %d", q);
       blocks += tn_blocks(t);
     }
   }
