@@ -550,9 +550,17 @@ def main():
                                  'whole_iter_mfma_frac': s['whole_iter_mfma_frac'], 'executed_tflops': s['executed_tflops'],
                                  'executed_mfma_frac': s['executed_mfma_frac'], 'final_losses': s['final_losses']}
         except Exception as e:                      # never lose the headline line to the secondary workload
-            if world > 1:
-                raise                               # ranks must stay in step: a one-rank failure cannot be skipped
             line['secondary'] = {'error': repr(e)[:200]}
+        if world > 1:
+            # ranks must stay in step: either every rank has the secondary line or none keeps it (a failure that is the
+            # same on every rank - an argument check, a missing path - is agreed on here and skipped; one rank failing
+            # INSIDE a collective cannot be helped from here)
+            import torch
+            import torch.distributed as dist
+            bad = torch.tensor([1.0 if 'error' in line['secondary'] else 0.0], device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if float(bad.item()) > 0 and 'error' not in line['secondary']:
+                line['secondary'] = {'error': 'another rank failed in the secondary workload'}
     if world == 1 and a.extra and a.workload == 'gtex' and a.batch == 32:
         # the other BASELINE.json configurations at batch 32 from the same tree (throughput only; their parity
         # cases are tests/test_gpu_fullsize.py): configs[0] E. coli (all genes / as shipped) and configs[4] wide
