@@ -412,10 +412,15 @@ bool tail_ok(const agx_cgan *h, int rows) {
 // three tiny ones, and the stacked layer-1 weight-gradient product runs over 2B + H1 rows - [real; fake; W_g^T] against
 // [D_1(real); D_1(fake); S] - instead of 3B.  Same algebra, other rounding: measured against the fp64 oracle like the
 // direct form (tests/test_gpu_fullsize.py); AGX_NO_GRAM selects the direct form (cross-check, tests/test_gpu_knobs.py).
+// twice the batch-to-width ratio from which the large-batch forms are taken (default 2: batch >= width - measured at GTEx size: 256 rows 157 k -> 194 k samples/s, 320 rows 161 k -> 218 k; AGX_GRAM_RATIO2: tuning)
+int gram_ratio2() {
+  static const int v = getenv("AGX_GRAM_RATIO2") ? std::max(2, atoi(getenv("AGX_GRAM_RATIO2"))) : 2;
+  return v;
+}
 bool gram_ok(const agx_cgan *h, int B) {
   static const bool off = getenv("AGX_NO_GRAM") != nullptr;
   const agx_mlp_desc_t &m = h->cfg.disc;
-  return !off && tail_ok(h, B) && 2 * B >= 3 * m.dims[1] && B <= h->Bm;
+  return !off && tail_ok(h, B) && 2 * B >= gram_ratio2() * m.dims[1] && B <= h->Bm;
 }
 // rows of the critic's stacked layer-1 weight-gradient product
 int dw1_rows(const agx_cgan *h, int B) { return gram_ok(h, B) ? 2 * B + h->cfg.disc.dims[1] : 3 * B; }
@@ -429,7 +434,7 @@ bool gen_fact_ok(const agx_cgan *h, int B) {
   static const bool off = getenv("AGX_NO_GRAM") != nullptr;
   const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;
   const int HL = gm.dims[gm.n_layers - 1], H1 = m.dims[1];
-  return !off && !gm.bn && 2 * B >= 3 * std::max(HL, H1) && B <= h->Bm && h->ldx % 4 == 0;
+  return !off && !gm.bn && 2 * B >= gram_ratio2() * std::max(HL, H1) && B <= h->Bm && h->ldx % 4 == 0;
 }
 // rows (K) of the generator's output-layer weight-gradient product
 int gen_dw_rows(const agx_cgan *h, int B) { return gen_fact_ok(h, B) ? h->cfg.disc.dims[1] : B; }

@@ -268,7 +268,7 @@ def test_adam_graph_iteration_is_bit_identical_to_eager(gpu):
     computed as for the eager call), so graph and eager runs agree bit for bit - weights, both moment slots,
     step counters, losses."""
     from adversarial_gene_expression_amd import tf_utils as T
-    p = make_problem(G=61, B=70, H=(24, 16), seed=63)
+    p = make_problem(G=61, B=70, H=(40, 16), seed=63)   # (hidden width > batch 32: the direct forms, as in the step functions)
     x32 = p['x'].astype(np.float32)
     out = []
     for use_graph in (False, True):
@@ -292,7 +292,7 @@ def test_graph_iteration_is_bit_identical_to_eager(gpu, p_aug):
     """train(use_graph=True) replays one hipGraph per iteration; with equal Philox seeds it must give
     exactly the weights, optimizer slots and losses of the eager step functions (ragged tail incl.)."""
     from adversarial_gene_expression_amd import tf_utils as T
-    p = make_problem(G=61, B=70, H=(24, 16), seed=61)
+    p = make_problem(G=61, B=70, H=(40, 16), seed=61)   # (hidden width > batch 32: the direct forms, as in the step functions)
     x32 = p['x'].astype(np.float32)
     out = []
     for use_graph in (False, True):
