@@ -27,7 +27,7 @@
 // * Inside a captured iteration the generator weights are constant over the nb_critic critic
 //   steps and the generator step (they change only at the iteration's end), so the generator
 //   runs ONCE on the nb_critic+1 stacked z batches; each step picks up its block of fake rows.
-// * Batches of at least 1.5 x the hidden widths never form a B x G matrix other than the real rows (gram_ok,
+// * Batches of at least the hidden widths never form a B x G matrix other than the real rows (gram_ok,
 //   gen_fact_ok, iter_ff below): the penalty's input-gradient terms go through the Gram matrix of W_1's gene rows, the
 //   generator's linear output layer (tf_utils.py:88) lets W_out W_g stand in for the generated rows.  Same algebra,
 //   other rounding order; DESIGN.md section 3 "Large batches".
@@ -403,7 +403,7 @@ bool tail_ok(const agx_cgan *h, int rows) {
   return !off && m.n_layers == 3 && m.dims[1] <= 256 && m.dims[2] <= 256 && h->ncov <= 256;
 }
 
-// Gram form of the gradient penalty (critic_core), for batches of at least 1.5 x the first hidden width: the
+// Gram form of the gradient penalty (critic_core), for batches of at least the first hidden width (gram_ratio2): the
 // input gradient g = d_1 . W_g^T (W_g = gene rows of W_1) is never formed.  With M = W_g^T W_g [H1, H1]:
 //   |g_i|^2 = d_1i . M . d_1i^T        (tf_utils.py:168-169)
 //   (f g) . W_g = f * (d_1 . M)        (second-order chain's first product)
@@ -429,7 +429,7 @@ int dw1_rows(const agx_cgan *h, int B) { return gram_ok(h, B) ? 2 * B + h->cfg.d
 // the critic's first-layer delta of the generated rows and h_L the generator's last hidden activations
 //   dX = d_1 W_g^T  is never formed:   dW_out = h_L^T dX = (d_1^T h_L)^T-as-TN . W_g^T        (K = H1 instead of B)
 //   db_out = colsum(dX) = colsum(d_1) . W_g^T;   dX W_out^T = d_1 . (W_out W_g)^T            (one H1 x HL x G product)
-// for batches of at least 1.5 x the wider of the two hidden widths.  AGX_NO_GRAM selects the direct form here too.
+// for batches of at least the wider of the two hidden widths.  AGX_NO_GRAM selects the direct form here too.
 bool gen_fact_ok(const agx_cgan *h, int B) {
   static const bool off = getenv("AGX_NO_GRAM") != nullptr;
   const agx_mlp_desc_t &m = h->cfg.disc, &gm = h->cfg.gen;

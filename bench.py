@@ -269,7 +269,7 @@ def run_gpu(workload, B, steps, warmup, world, rank, nb_critic=5, roofline=True)
     flops_iter = algorithmic_flops_per_iter(G, V, n_num, H, Z, B, nb_critic) if len(H) == 2 else None
     # what the launches of one iteration actually multiply (sum of their own 2MNK tags): less than the SURVEY 8(d) count
     # of the reference's algorithm, which whole_iter_* prices - the layer-1 forward of the interpolated rows comes from
-    # the real and fake rows' by linearity, and from 1.5 x the hidden width on the penalty's input-gradient terms go
+    # the real and fake rows' by linearity, and from a batch of the hidden width on the penalty's input-gradient terms go
     # through the Gram matrix of W_1's gene rows (cgan.hip gram_ok)
     flops_exec = sum(v['flops'] for v in disc_prof.values()) / nprobe
     res = dict(value=Bg * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roof, final_losses=final_losses,

@@ -36,7 +36,7 @@ def _check_grads(got, want, rtol=3e-5):
 CFGS = [dict(), dict(B=1, seed=2), dict(B=12, H=(16,), seed=3), dict(B=33, H=(24, 16), G=130, seed=4),
         dict(B=7, H=(12, 10, 8), V=(6, 8, 5, 11, 5, 3, 5), Z=10, seed=5),
         dict(B=4, n_num=2, num_zero=False, seed=7), dict(B=32, G=300, H=(128, 128), V=(15, 3), Z=64, seed=8),
-        # batches of >= 1.5 x the hidden widths: Gram form of the penalty, factored generator step (cgan.hip gram_ok, gen_fact_ok)
+        # batches of >= the hidden widths: Gram form of the penalty, factored generator step (cgan.hip gram_ok, gen_fact_ok)
         dict(B=40, H=(16, 8), seed=9), dict(B=48, G=130, H=(24, 16), n_num=2, num_zero=False, seed=10),
         # direct form on the 64-wide tiling with G mod 64 in 1..32: the last tile's second 32-column block has no slab of
         # squared-norm partials (it used to land on the next row's slab 0: critic loss off by 2e-3 at this shape)
@@ -418,7 +418,7 @@ def test_large_batch_graph_paths_match_eager(gpu, p_aug):
         out.append((gen.get_weights(), disc.get_weights(), tr))
     (gw0, dw0, tr0), (gw1, dw1, tr1) = out
     if p_aug == 0:
-        # without augmentation the captured iteration at this batch (>= 1.5 x the hidden widths) never forms the generated
+        # without augmentation the captured iteration at this batch (>= the hidden widths) never forms the generated
         # rows (cgan.hip iter_ff) while the step functions do: the same algebra, rounded differently
         for a, b in zip(gw0 + dw0, gw1 + dw1):
             np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)

@@ -55,7 +55,7 @@ def test_knob_sequence_computes_the_default_iteration(gpu, tmp_path, default_run
 
 @pytest.mark.parametrize('knob', ['AGX_NO_GRAM', 'AGX_NO_FF', 'AGX_NO_FUSED_OPT', 'AGX_NO_TAIL'])
 def test_gram_form_computes_the_direct_form(gpu, tmp_path, knob):
-    """Batches of at least 1.5 x the first hidden width take the Gram form of the gradient penalty (cgan.hip gram_ok:
+    """Batches of at least the first hidden width take the Gram form of the gradient penalty (cgan.hip gram_ok:
     |d_1 W_g^T|^2 = d_1 (W_g^T W_g) d_1^T, and so on): same algebra as the direct form (AGX_NO_GRAM), other rounding.  The
     full-size 512-row cases of test_gpu_fullsize.py and test_gpu_split8.py compare the Gram form with the oracle.
     On top of it the one-GPU iteration without augmentation never forms the generated rows (record_iteration `ff`:
