@@ -40,7 +40,9 @@ CFGS = [dict(), dict(B=1, seed=2), dict(B=12, H=(16,), seed=3), dict(B=33, H=(24
         dict(B=40, H=(16, 8), seed=9), dict(B=48, G=130, H=(24, 16), n_num=2, num_zero=False, seed=10),
         # direct form on the 64-wide tiling with G mod 64 in 1..32: the last tile's second 32-column block has no slab of
         # squared-norm partials (it used to land on the next row's slab 0: critic loss off by 2e-3 at this shape)
-        dict(B=192, G=4297, H=(160, 96), V=(6, 8, 5), Z=10, seed=11)]
+        dict(B=192, G=4297, H=(160, 96), V=(6, 8, 5), Z=10, seed=11),
+        # batch == first hidden width: W_g^T fills the interpolated rows of the stacked input exactly
+        dict(B=24, G=130, H=(24, 16), seed=12)]
 
 
 @pytest.mark.parametrize('cfg', CFGS)
