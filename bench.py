@@ -551,6 +551,22 @@ def main():
                                  'executed_mfma_frac': s['executed_mfma_frac'], 'final_losses': s['final_losses']}
         except Exception as e:                      # never lose the headline line to the secondary workload
             line['secondary'] = {'error': repr(e)[:200]}
+        if world == 1 and 'error' not in line['secondary'] and not os.environ.get('AGX_NO_GRAM') and not os.environ.get('AGX_BENCH_NO_AB'):
+            # the same 512-row workload with the DIRECT forms of the large-batch algebra (AGX_NO_GRAM=1: B x G input gradient
+            # formed, generated rows materialised) in a child process - the library reads its knobs once -
+            # so that the line carries its own A/B: what the algebra bought on this box
+            try:
+                import subprocess
+                env = dict(os.environ, AGX_NO_GRAM='1')
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--batch', '512', '--workload', a.workload,
+                                    '--steps', str(max(10, a.steps // 8)), '--warmup', str(max(3, a.warmup // 4)), '--no-secondary',
+                                    '--no-extra', '--no-cpu-baseline', '--corr-n', '0'], env=env, capture_output=True, text=True, timeout=240)
+                dl = json.loads(r.stdout.strip().splitlines()[-1])
+                line['secondary']['direct_forms'] = {'value': dl['value'], 'unit': 'samples/s', 'ms_per_step': dl['ms_per_step'],
+                                                     'executed_mfma_frac': dl.get('executed_mfma_frac'),
+                                                     'note': 'AGX_NO_GRAM=1, same workload, child process'}
+            except Exception as e:
+                line['secondary']['direct_forms'] = {'error': repr(e)[:200]}
         if world > 1:
             # ranks must stay in step: either every rank has the secondary line or none keeps it (a failure that is the
             # same on every rank - an argument check, a missing path - is agreed on here and skipped; one rank failing
