@@ -789,13 +789,21 @@ __device__ __forceinline__ void tn_wave_tile(const agx::TnJobs::Job &t, int tile
     for (int r = 0; r < 16; ++r) acc_out[r] = acc[r];
     return;
   }
-  if (acc_out) {   // the other waves' shares, in wave order
-    const int nother = t.K > 1024 ? 7 : 3;
-    for (int w = 0; w < nother; ++w)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += acc_out[(w * 16 + r) * 64 + lane];
-  }
   if (nv) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < t.M) t.C[(size_t)row * t.ldc + n0 + i] = acc[r];
+    }
+  }
+}
+
+// the 32x32 tile `tile` of C from a wave's accumulator image (C/D map of the 32x32 MFMA, see tn_wave_tile)
+__device__ __forceinline__ void tn_store_tile(const agx::TnJobs::Job &t, int tile, const float *acc) {
+  const int tiles_n = (t.N + 31) / 32;
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+  if (n0 + i < t.N) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -847,19 +855,27 @@ __global__ void __launch_bounds__(1024) small_grads_kernel(const SmallPlan plan,
     // on one CU queue 4 waves' MFMAs per SIMD: the launch grew from 8.5 to 13 us); waves 4..15 leave
     const agx::TnJobs::Job &t = tn.job[jidx];
     if (tn_split_k(t.K)) {
-      // long K (S and Hx^T d_1 at 512 rows: 22 us as one wave per tile): the block's four waves take a quarter of K each,
-      // waves 1..3 leave their sums in LDS, wave 0 adds them in wave order and stores
+      // long K (S and Hx^T d_1 at 512 rows: 22 us as one wave per tile): the block's waves take a share of K each (four or
+      // eight), leave their sums in LDS, and wave 0 adds them in wave order and stores
       const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      const int nw = t.K > 1024 ? 8 : 4;   // (eight shares from 1024 rows on: the hidden-layer gradient over 3B = 1536 rows)
+      const int nw = t.K > 1024 ? 8 : 4;   // (eight shares from 1024 rows on: the hidden-layer gradient over 3B = 1536 rows;
+      //  sixteen in two stages measured no different: 16.3 against 16.4 us - the launch's long pole is elsewhere by then)
       const int kq = (((t.K + nw - 1) / nw) + 7) & ~7;
+      // (every wave, wave 0 too, multiplies its share BEFORE the barrier: wave 0 used to start its own share behind it,
+      //  so a job took two shares' time - 22.9 against 16.4 us per launch at 512 rows)
+      float part[16];
+      if (w < nw) tn_wave_tile(t, blk, w * kq, min(t.K, (w + 1) * kq), false, part);
       if (w >= 1 && w < nw) {
-        float part[16];
-        tn_wave_tile(t, blk, w * kq, min(t.K, (w + 1) * kq), false, part);
 #pragma unroll
         for (int r = 0; r < 16; ++r) svec[((w - 1) * 16 + r) * 64 + lane] = part[r];
       }
       __syncthreads();
-      if (w == 0) tn_wave_tile(t, blk, 0, min(t.K, kq), true, svec);
+      if (w == 0) {
+        for (int o = 0; o < nw - 1; ++o)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[r] += svec[(o * 16 + r) * 64 + lane];
+        tn_store_tile(t, blk, part);
+      }
       return;
     }
     if (threadIdx.x < 256) tn_wave_tile(t, blk * 4 + (int)(threadIdx.x >> 6), 0, t.K, true, nullptr);
